@@ -1,0 +1,308 @@
+"""CPU oracle: plain numpy/scipy restatement of the PyTEMDiags hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the shipped package (``pytemdiags_amd``) imports
+this module; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may call it, and only as the checker / timed baseline.
+
+Parity status: PINNED.  The restatement is checked (tests/test_oracle_golden.py) against
+golden vectors in ``tests/golden/*.npz`` that were produced by running the *unmodified*
+reference source from ``/root/reference`` in the build container (generator:
+``tools/make_goldens.py``), and against the analytic known-answers the reference's own
+test-suite intends to pin (``PyTEMDiags/tests/tests_sph_zonal_mean.py:331-347, 465-475``).
+
+All arrays are plain ``ndarray`` laid out ``(ncol | lat, lev, time)``.  Every function cites
+the reference file:line (relative to /root/reference/PyTEMDiags/) whose arithmetic it follows.
+
+Two association modes of the zonal-mean operator are provided:
+
+* ``mode='literal'``    -- exactly the reference's operation order: dense
+  ``Y0inv = lstsq(Y0, I_N)[0]`` (sph_zonal_mean.py:389) and ``(Y @ Y0inv) @ A``
+  (sph_zonal_mean.py:251).  O(N^2) memory: small grids only.
+* ``mode='factorised'`` -- the same linear operator written ``Y @ (G^-1 (Y0^T A))`` with
+  ``G = Y0^T Y0``.  O(N K) memory; this is the association the HIP engine uses and the
+  yard-stick at BASELINE.json's full sizes.
+"""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+import scipy.linalg
+import scipy.special
+
+# --- constants.py:6-14 (values are part of parity; note the truncated pi) -------------
+P0 = 101325
+R = 287.058
+Cp = 1004.64
+g0 = 9.80665
+a = 6.37123e6
+Om = 7.29212e-5
+k = R / Cp
+H = 7 * 1e3
+pi = 3.14159
+
+_trapz = getattr(np, "trapezoid", None) or np.trapz   # np.trapz (tem_util.py:232) was renamed in numpy 2
+
+
+# =================================================================================================
+# basis  (sph_zonal_mean.py:358-370)
+# =================================================================================================
+def ylm0_matrix(lat_deg, L):
+    """Y[i, l] = Re Y_l^0(colat_i), colat = deg2rad(90 - lat)   (sph_zonal_mean.py:360-363).
+
+    The reference calls ``scipy.special.sph_harm(0, l, 0, colat).real``; that function is
+    deprecated (removed in SciPy 1.17), ``sph_harm_y(l, 0, colat, 0)`` is the same quantity.
+    """
+    lat_deg = np.asarray(lat_deg, dtype=np.float64)
+    colat = np.deg2rad(90 - lat_deg)
+    Y = np.zeros((lat_deg.size, L + 1))
+    legacy = getattr(scipy.special, "sph_harm", None)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for ll in range(L + 1):
+            if legacy is not None:
+                Y[:, ll] = legacy(0, ll, 0, colat).real
+            else:  # pragma: no cover - newer scipy
+                Y[:, ll] = scipy.special.sph_harm_y(ll, 0, colat, 0).real
+    return Y
+
+
+def ylm0_matrix_recurrence(lat_deg, L):
+    """Same matrix by the Legendre three-term recurrence (what the device kernel does):
+    Y_l^0 = sqrt((2l+1)/(4 pi)) P_l(x), x = cos(colat);  (l+1) P_{l+1} = (2l+1) x P_l - l P_{l-1}.
+    """
+    x = np.cos(np.deg2rad(90 - np.asarray(lat_deg, dtype=np.float64)))
+    Y = np.zeros((x.size, L + 1))
+    pm1 = np.ones_like(x)
+    Y[:, 0] = np.sqrt(1.0 / (4 * np.pi))
+    if L >= 1:
+        pc = x.copy()
+        Y[:, 1] = np.sqrt(3.0 / (4 * np.pi)) * pc
+        for l in range(1, L):
+            pn = ((2 * l + 1) * x * pc - l * pm1) / (l + 1)
+            pm1, pc = pc, pn
+            Y[:, l + 1] = np.sqrt((2 * l + 3) / (4 * np.pi)) * pc
+    return Y
+
+
+# =================================================================================================
+# zonal averager  (sph_zonal_mean.py:35-422)
+# =================================================================================================
+class ZonalAverager:
+    """Restatement of ``sph_zonal_averager`` (arithmetic only; no NetCDF map cache)."""
+
+    def __init__(self, lat, lat_out, L, weights=None, mode="literal", basis="scipy"):
+        self.lat = np.asarray(lat, dtype=np.float64)
+        self.lat_out = np.asarray(lat_out, dtype=np.float64)
+        self.L = int(L)
+        self.N = self.lat.size            # sph_zonal_mean.py:154
+        self.M = self.lat_out.size        # sph_zonal_mean.py:155
+        self.mode = mode
+        # weights scaled to the unit-sphere area (sph_zonal_mean.py:180-181); not in place here
+        self.weights = None if weights is None else np.asarray(weights, dtype=np.float64) * 4 * np.pi
+        build = ylm0_matrix if basis == "scipy" else ylm0_matrix_recurrence
+        self.Y0 = build(self.lat, self.L)        # sph_zonal_mean.py:360-363
+        self.Y0p = build(self.lat_out, self.L)   # sph_zonal_mean.py:367-370
+        self.Y0inv = None
+        self.Ginv = None
+        if self.weights is not None:
+            if self.weights.size != self.N:      # sph_zonal_mean.py:353-354
+                raise RuntimeError("number of weights must equal number of native grid latitudes!")
+            # Y0inv = Y0^T diag(w)  (sph_zonal_mean.py:385) without forming the N x N diagonal
+            self.Y0inv = self.Y0.T * self.weights[None, :]
+        elif mode == "literal":
+            # sph_zonal_mean.py:389
+            self.Y0inv = scipy.linalg.lstsq(self.Y0, np.identity(self.N))[0]
+        else:
+            G = self.Y0.T @ self.Y0
+            self.Ginv = np.linalg.inv(G)
+
+    # sph_zonal_mean.py:393-394  (sanity numbers the reference prints)
+    def sanity(self):
+        if self.Y0inv is not None:
+            P = self.Y0inv @ self.Y0
+        else:
+            P = self.Ginv @ (self.Y0.T @ self.Y0)
+        diagsum = np.sum(np.diagonal(P))
+        return diagsum, np.sum(P) - diagsum
+
+    def coefficients(self, AA):
+        """C = Y0inv @ AA  ([K, D])."""
+        if self.Y0inv is not None:
+            return self.Y0inv @ AA
+        return self.Ginv @ (self.Y0.T @ AA)
+
+    def _generic(self, A, Y):
+        """sph_zonal_mean.py:187-283."""
+        A = np.asarray(A)
+        if np.sum(np.isnan(A)) > 0:               # :219-221
+            raise RuntimeError("Variable has nans! Spectral zonal averager cannot handle nans; "
+                               "please replace or remove them")
+        if A.shape[0] != self.N:                  # :234-237
+            raise RuntimeError("Expected the first (leftmost) dimension to be ncol of length %d" % self.N)
+        prec = A.dtype                            # :240
+        shape = A.shape
+        DD = 1 if A.ndim == 1 else int(np.prod(shape[1:]))
+        AA = A.reshape((self.N, DD))              # :246
+        if self.mode == "literal" or self.weights is not None:
+            Abar = np.matmul(np.matmul(Y, self.Y0inv), AA)      # :251
+        else:
+            Abar = Y @ (self.Ginv @ (self.Y0.T @ AA))
+        Abar = Abar.reshape((Y.shape[0],) + tuple(shape[1:]))   # :255
+        return Abar.astype(prec)                  # :282
+
+    def zonal_mean(self, A):                      # :291-296
+        return self._generic(A, self.Y0p)
+
+    def zonal_mean_native(self, A):               # :285-290
+        return self._generic(A, self.Y0)
+
+
+# =================================================================================================
+# tem_util.py numerics
+# =================================================================================================
+def multiply_lat(A, lat):      # tem_util.py:80
+    return np.einsum("ijk,i->ijk", A, lat)
+
+
+def multiply_p(A, p):          # tem_util.py:117
+    return np.einsum("ijk,j->ijk", A, p)
+
+
+def lat_gradient(A, lat):      # tem_util.py:154
+    return np.gradient(A, lat, axis=0)
+
+
+def p_gradient(A, p):          # tem_util.py:192
+    return np.gradient(A, p, axis=1)
+
+
+def p_integral(A, p):          # tem_util.py:230-232  (cumulative trapezoid from the model top)
+    out = np.zeros(A.shape)
+    for kk in range(len(p)):
+        out[:, kk, :] = _trapz(A[:, :kk + 1, :], p[:kk + 1], axis=1)
+    return out
+
+
+def zm_latitudes(zm_dlat=1, zm_pole_points=False):
+    """tem_diagnostics.py:388-396."""
+    tol = 1e-6
+    assert (180 / zm_dlat).is_integer(), "180 must be divisible by dlat_out"
+    lat_zm = np.arange(-90, 90 + zm_dlat, zm_dlat)
+    if lat_zm[-1] > 90 + tol:
+        lat_zm = lat_zm[:-1]
+    if not zm_pole_points:
+        lat_zm = (lat_zm[1:] + lat_zm[:-1]) / 2
+    return lat_zm
+
+
+# =================================================================================================
+# TEM pipeline  (tem_diagnostics.py:215-797)
+# =================================================================================================
+ZONAL_ATTRS = ("ub", "vb", "thetab", "wapb", "upvpb", "upwappb", "vptpb", "dub_dp", "dthetab_dp",
+               "ubcoslat", "dubcoslat_dlat", "psi", "psicoslat", "dpsicoslat_dlat", "dpsi_dp",
+               "int_vbdp")
+NATIVE_ATTRS = ("up", "vp", "thetap", "wapp", "upvp", "upwapp", "vptp")
+RESULTS = ("vtem", "omegatem", "wtem", "psitem", "epfy", "epfz", "epdiv",
+           "utendepfd", "utendvtem", "utendwtem")
+
+
+class TEMOracle:
+    """Restatement of ``TEMDiagnostics`` (no tracers) on ndarrays ``(ncol, lev, time)``.
+
+    ``plev`` in hPa.  Descending ``plev`` is flipped exactly like tem_diagnostics.py:372-382.
+    """
+
+    def __init__(self, ua, va, ta, wap, lat_native, plev, p0=P0, zm_dlat=1, L=50,
+                 zm_pole_points=False, mode="literal", basis="scipy"):
+        ua, va, ta, wap = (np.asarray(x) for x in (ua, va, ta, wap))
+        plev = np.asarray(plev)
+        if plev[0] > plev[-1]:                                   # :372-382
+            ua, va, ta, wap = (x[:, ::-1, :] for x in (ua, va, ta, wap))
+            plev = plev[::-1]
+        self.ua, self.va, self.ta, self.wap = ua, va, ta, wap
+        self.plev = plev
+        self.p0 = p0
+        self.p = plev * 100                                      # :385
+        self.L = L
+        self.lat = zm_latitudes(zm_dlat, zm_pole_points)         # :388-396
+        self.f = (2 * Om * np.sin(self.lat * np.pi / 180))[:, None, None]   # :401, :405
+        self.coslat = np.cos(self.lat * np.pi / 180)             # :402
+        self.ZM = ZonalAverager(lat_native, self.lat, L, mode=mode, basis=basis)   # :243-248
+        zm, zmn = self.ZM.zonal_mean, self.ZM.zonal_mean_native
+
+        # theta = T (p0/p)^k   (:498); einsum with the fp64 p promotes theta to fp64 (Q5)
+        self.theta = multiply_p(self.ta, (self.p0 / self.p) ** k)
+
+        # zonal means and eddies  (:515-530)
+        self.ub = zm(ua);            self.up = ua - zmn(ua)
+        self.vb = zm(va);            self.vp = va - zmn(va)
+        self.thetab = zm(self.theta); self.thetap = self.theta - zmn(self.theta)
+        self.wapb = zm(wap);         self.wapp = wap - zmn(wap)
+
+        # fluxes  (:547-557)
+        self.upvp = self.up * self.vp;        self.upvpb = zm(self.upvp)
+        self.upwapp = self.up * self.wapp;    self.upwappb = zm(self.upwapp)
+        self.vptp = self.vp * self.thetap;    self.vptpb = zm(self.vptp)
+
+        # derivatives  (:579-599)
+        latr = np.deg2rad(self.lat)
+        self.dub_dp = p_gradient(self.ub, self.p)
+        self.dthetab_dp = p_gradient(self.thetab, self.p)
+        self.ubcoslat = multiply_lat(self.ub, self.coslat)
+        self.dubcoslat_dlat = lat_gradient(self.ubcoslat, latr)
+        self.psi = self.vptpb / self.dthetab_dp                   # :590
+        self.psicoslat = multiply_lat(self.psi, self.coslat)
+        self.dpsicoslat_dlat = lat_gradient(self.psicoslat, latr)
+        self.dpsi_dp = p_gradient(self.psi, self.p)
+        self.int_vbdp = p_integral(self.vb, self.p)
+
+    # ---- diagnostics (each cast to an input dtype exactly where the reference does) ----
+    def vtem(self):          # :615-628
+        return (self.vb - self.dpsi_dp).astype(self.va.dtype)
+
+    def omegatem(self):      # :632-645
+        return (self.wapb + multiply_lat(self.dpsicoslat_dlat, 1 / (a * self.coslat))).astype(self.wap.dtype)
+
+    def wtem(self):          # :649-663
+        return multiply_p(self.omegatem(), -H / self.p).astype(self.wap.dtype)
+
+    def psitem(self):        # :667-680  (NB truncated pi)
+        return (2 * pi * a / g0 * multiply_lat(self.int_vbdp - self.psi, self.coslat)).astype(self.va.dtype)
+
+    def epfy(self):          # :684-698
+        x = multiply_lat(self.dub_dp * self.psi - self.upvpb, a * self.coslat)
+        return multiply_p(x, self.p / self.p0).astype(self.ua.dtype)
+
+    def epfz(self):          # :702-716
+        x = self.f - multiply_lat(self.dubcoslat_dlat, 1 / (a * self.coslat))
+        return (-H / self.p0 * multiply_lat((x * self.psi - self.upwappb), a * self.coslat)).astype(self.ua.dtype)
+
+    def epdiv(self):         # :720-742  (consumes the already-cast epfy/epfz)
+        Fphi = multiply_p(self.epfy(), self.p0 / self.p)
+        Fp = self.epfz() * -self.p0 / H
+        Fphicoslat = multiply_lat(Fphi, self.coslat)
+        dFphicoslat_dlat = lat_gradient(Fphicoslat, np.deg2rad(self.lat))
+        dFp_dp = p_gradient(Fp, self.p)
+        return (multiply_lat(dFphicoslat_dlat, 1 / (a * self.coslat)) + dFp_dp).astype(self.ua.dtype)
+
+    def utendepfd(self):     # :746-759
+        return multiply_lat(self.epdiv(), 1 / (a * self.coslat)).astype(self.ua.dtype)
+
+    def utendvtem(self):     # :763-779
+        diff = self.f - multiply_lat(self.dubcoslat_dlat, 1 / (a * self.coslat))
+        return (self.vtem() * diff).astype(self.ua.dtype)
+
+    def utendwtem(self):     # :783-797
+        return (-self.omegatem() * self.dub_dp).astype(self.ua.dtype)
+
+    def results(self):
+        return {n: getattr(self, n)() for n in RESULTS}
+
+    def zonal_attrs(self):
+        return {n: getattr(self, n) for n in ZONAL_ATTRS}
+
+
+def run_tem(ua, va, ta, wap, lat_native, plev, **kw):
+    """Convenience: dict of the ten GM16 Table-A1 outputs."""
+    return TEMOracle(ua, va, ta, wap, lat_native, plev, **kw).results()

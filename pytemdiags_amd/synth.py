@@ -1,0 +1,87 @@
+"""Deterministic synthetic grids and fields for tests and benchmarks (host / numpy side).
+
+Nothing here is on the product path: it only manufactures inputs of the shapes
+named in BASELINE.json.
+
+* ``cubed_sphere_gll(ne)``  -- unique GLL (np=4) nodes of an equiangular cubed sphere,
+  6*ne^2*9+2 points (866 / 3458 / 48602 / 777602 / 3110402 for ne4/8/30/120/240).
+* ``pressure_levels(nlev)`` -- log-spaced 1..1000 hPa, top -> bottom.
+* ``analytic_fields(...)``  -- stably stratified T, jet-like u, wavy v / omega
+  (+ optional Gaussian noise from ``np.random.default_rng``).
+
+The device-side generator with the same analytic part (noise from a counter hash)
+lives in csrc/synth.hip and is exposed as ``temx_synth_fields``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+__all__ = ["cubed_sphere_gll", "pressure_levels", "analytic_fields", "ncol_of_ne"]
+
+
+def ncol_of_ne(ne: int) -> int:
+    return 6 * ne * ne * 9 + 2
+
+
+def cubed_sphere_gll(ne: int):
+    """Return (lat_deg, lon_deg) of the unique np=4 GLL nodes of an ne x ne x 6 cubed sphere.
+
+    Points are sorted lexicographically by rounded (x, y, z) so the order is
+    deterministic but *unstructured* with respect to latitude.
+    """
+    gll = np.array([-1.0, -1.0 / np.sqrt(5.0), 1.0 / np.sqrt(5.0), 1.0])
+    edges = np.linspace(-np.pi / 4, np.pi / 4, ne + 1)
+    mid = 0.5 * (edges[1:] + edges[:-1])
+    half = 0.5 * (edges[1:] - edges[:-1])
+    ang = (mid[:, None] + half[:, None] * gll[None, :]).ravel()
+    ang = np.unique(np.round(ang, 14))
+    assert ang.size == 3 * ne + 1
+    t = np.tan(ang)
+    X, Y = np.meshgrid(t, t, indexing="ij")
+    X = X.ravel()
+    Y = Y.ravel()
+    one = np.ones_like(X)
+    faces = [
+        (one, X, Y), (-one, -X, Y), (-X, one, Y),
+        (X, -one, Y), (-Y, X, one), (Y, X, -one),
+    ]
+    P = np.concatenate([np.stack(f, axis=1) for f in faces], axis=0)
+    P /= np.linalg.norm(P, axis=1, keepdims=True)
+    P = np.unique(np.round(P, 12), axis=0)
+    assert P.shape[0] == ncol_of_ne(ne), (P.shape, ncol_of_ne(ne))
+    P /= np.linalg.norm(P, axis=1, keepdims=True)
+    lat = np.rad2deg(np.arcsin(np.clip(P[:, 2], -1.0, 1.0)))
+    lon = np.mod(np.rad2deg(np.arctan2(P[:, 1], P[:, 0])), 360.0)
+    return lat, lon
+
+
+def pressure_levels(nlev: int) -> np.ndarray:
+    """plev in hPa, ascending pressure (model top first)."""
+    return np.exp(np.linspace(np.log(1.0), np.log(1000.0), nlev))
+
+
+def analytic_fields(lat_deg, lon_deg, plev_hpa, nt, noise=0.1, seed=0, dtype=np.float64):
+    """Return (ua, va, ta, wap), each ``[ncol][nlev][nt]`` C-contiguous.
+
+    Noise is drawn in the order u, v, T, omega from ``default_rng(seed)``.
+    """
+    phi = np.deg2rad(np.asarray(lat_deg, dtype=np.float64))[:, None, None]
+    lam = np.deg2rad(np.asarray(lon_deg, dtype=np.float64))[:, None, None]
+    p = np.asarray(plev_hpa, dtype=np.float64)[None, :, None]
+    t = np.arange(nt, dtype=np.float64)[None, None, :]
+    z = -7.0 * np.log(p / 1000.0)
+    s, c = np.sin(phi), np.cos(phi)
+    T = (300.0 - 60.0 * s**2 - 6.5 * np.minimum(z, 12.0) + 2.0 * np.maximum(z - 20.0, 0.0)
+         + 3.0 * np.cos(3 * lam + 0.3 * t) * c)
+    u = (30.0 * np.sin(2 * phi) ** 2 * np.exp(-((z - 12.0) / 8.0) ** 2)
+         + 8.0 * np.sin(4 * lam + 0.2 * t) * c**2 + 0.0 * z)
+    v = (6.0 * np.cos(4 * lam + 0.2 * t) * c**2 * np.exp(-((z - 10.0) / 10.0) ** 2)
+         + 0.5 * np.sin(2 * phi) + 0.0 * t)
+    w = (0.05 * np.sin(4 * lam + 0.2 * t + 0.7) * c**2 + 0.01 * np.cos(3 * phi) + 0.0 * z)
+    shape = (phi.shape[0], p.shape[1], nt)
+    u, v, T, w = (np.broadcast_to(a, shape).copy() for a in (u, v, T, w))
+    if noise:
+        rng = np.random.default_rng(seed)
+        for a in (u, v, T, w):
+            a += noise * rng.standard_normal(shape)
+    return tuple(np.ascontiguousarray(a.astype(dtype)) for a in (u, v, T, w))
