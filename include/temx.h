@@ -1,0 +1,178 @@
+/* temx.h -- C ABI of libtemx.so, the MI355X (gfx950) TEM-diagnostics engine.
+ *
+ * The reference (jhollowed/PyTEMDiags) is pure Python and has no FFI: its boundary for the
+ * hot path is the public Python API.  These entry points are what a ctypes binding inside
+ * the reference would call in place of its numpy/scipy call sites; each one cites the
+ * reference code it replaces (paths relative to PyTEMDiags/).  INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer on the plan's device unless the name ends in _host;
+ *   - fields are row-major [ncol][D] with D = nlev*nt (time fastest), exactly the
+ *     (N, DD) reshape of sph_zonal_mean.py:243-246 after _config_dims' transpose
+ *     (tem_diagnostics.py:343-357);
+ *   - dtype: TEMX_F64 or TEMX_F32 input fields; all arithmetic and all outputs are fp64
+ *     (the reference's matrices are fp64, so its matmul accumulates in fp64,
+ *     sph_zonal_mean.py:278-282; the Python front end applies the final astype);
+ *   - stream: a hipStream_t passed as void* (NULL = default stream); all compute entry
+ *     points are asynchronous and stream ordered, they allocate nothing once the plan's
+ *     workspace has been sized (first call for a given D);
+ *   - return value: 0 (TEMX_OK) or a negative TEMX_E* code; temx_last_error() gives the
+ *     thread-local message;
+ *   - a plan is bound to one device and is not thread safe; different plans are independent.
+ */
+#ifndef TEMX_H
+#define TEMX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct temx_plan temx_plan;
+
+enum { TEMX_F64 = 0, TEMX_F32 = 1 };
+
+enum {
+  TEMX_OK = 0,
+  TEMX_EINVAL = -1,   /* bad argument */
+  TEMX_EHIP = -2,     /* HIP runtime error (no device, launch failure, ...) */
+  TEMX_ENOMEM = -3,   /* device allocation failed */
+  TEMX_ERANK = -4,    /* Gram matrix not positive definite (rank-deficient Y0) */
+  TEMX_ESTATE = -5,   /* call order violated (plan not finalised, TEM levels not set, ...) */
+  TEMX_EUNSUPPORTED = -6
+};
+
+enum { TEMX_DEFER_FINALIZE = 1 };
+
+/* which matrix temx_get_matrix copies */
+enum {
+  TEMX_MAT_Y0 = 0,    /* [N][K]   sph_zonal_mean.py:360-363 */
+  TEMX_MAT_Y0P = 1,   /* [M][K]   sph_zonal_mean.py:367-370 */
+  TEMX_MAT_GRAM = 2,  /* [K][K]   Y0^T Y0 (this rank's rows only until finalised with a global G) */
+  TEMX_MAT_GINV = 3,  /* [K][K]   inverse Gram; Y0inv = GINV . Y0^T */
+  TEMX_MAT_Y0INV = 4  /* [K][N]   pinv(Y0) as the reference stores it, sph_zonal_mean.py:389 */
+};
+
+/* order of the ten GM16 Table-A1 results in the results buffer (tem_diagnostics.py:1018-1022) */
+enum {
+  TEMX_R_VTEM = 0, TEMX_R_OMEGATEM, TEMX_R_WTEM, TEMX_R_PSITEM, TEMX_R_EPFY, TEMX_R_EPFZ,
+  TEMX_R_EPDIV, TEMX_R_UTENDEPFD, TEMX_R_UTENDVTEM, TEMX_R_UTENDWTEM, TEMX_NRESULTS
+};
+
+/* order of the zonal-grid intermediates (tem_diagnostics.py:1009-1017, zonal ones) */
+enum {
+  TEMX_Z_UB = 0, TEMX_Z_VB, TEMX_Z_THETAB, TEMX_Z_WAPB, TEMX_Z_UPVPB, TEMX_Z_UPWAPPB,
+  TEMX_Z_VPTPB, TEMX_Z_DUB_DP, TEMX_Z_DTHETAB_DP, TEMX_Z_UBCOSLAT, TEMX_Z_DUBCOSLAT_DLAT,
+  TEMX_Z_PSI, TEMX_Z_PSICOSLAT, TEMX_Z_DPSICOSLAT_DLAT, TEMX_Z_DPSI_DP, TEMX_Z_INT_VBDP,
+  TEMX_NZONAL
+};
+
+/* order of the native-grid eddy fields (tem_diagnostics.py:517-529, 547-555) */
+enum {
+  TEMX_E_UP = 0, TEMX_E_VP, TEMX_E_THETAP, TEMX_E_WAPP, TEMX_E_UPVP, TEMX_E_UPWAPP, TEMX_E_VPTP,
+  TEMX_NEDDY
+};
+
+int temx_version(void);
+const char* temx_last_error(void);
+int temx_device_count(void);
+
+/* ---- plan: replaces sph_zonal_averager.__init__ + sph_compute_matrices ----------------------
+ * (sph_zonal_mean.py:36-181, 302-422).  Builds Y0 (N x K) and Y0p (M x K), K = L+1, on the
+ * device by the normalised Legendre recurrence, the Gram matrix G = Y0^T Y0 with the MFMA
+ * projection kernel, and (unless TEMX_DEFER_FINALIZE) factorises G on the host (Cholesky),
+ * which replaces lstsq(Y0, I_N) (sph_zonal_mean.py:389): pinv(Y0) = G^-1 Y0^T.
+ * lat_deg_host[ncol], lat_out_deg_host[M] in degrees.  L <= 63 in this version. */
+int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
+                     const double* lat_deg_host, const double* lat_out_deg_host, int flags);
+
+/* ncol-sharded use: each rank creates its plan with TEMX_DEFER_FINALIZE over its own
+ * columns, copies its local Gram out (temx_get_matrix(TEMX_MAT_GRAM)), all-reduces it, and
+ * hands the global G back here.  G_host == NULL finalises with the local Gram. */
+int temx_plan_finalize(temx_plan* plan, const double* G_host /* [K][K] or NULL */);
+
+/* weights mode of the operator (sph_zonal_mean.py:180-181, 383-386): Y0inv = Y0^T diag(4 pi w).
+ * Replaces the Gram solve by a per-column scale; call instead of temx_plan_finalize. */
+int temx_plan_set_weights(temx_plan* plan, const double* weights_host /* [ncol], sums to 1 */);
+
+void temx_plan_destroy(temx_plan* plan);
+
+int temx_get_matrix(temx_plan* plan, int which, double* dst, void* stream);
+
+/* ---- operator API: replaces _sph_zonal_mean_generic (sph_zonal_mean.py:187-283) ------------ */
+
+/* B[K][D] = Y0^T A  (this rank's columns; raw sums, before G^-1).  A is [ncol][D]. */
+int temx_project(temx_plan* plan, const void* A, int dtype, int64_t D, double* B, void* stream);
+
+/* out = (Y . Y0inv) . A   (sph_zonal_mean.py:251);  native == 0: Y = Y0p, out is [M][D]
+ * (sph_zonal_mean, :291);  native != 0: Y = Y0, out is [ncol][D] (sph_zonal_mean_native, :285).
+ * out is fp64. */
+int temx_zonal_mean(temx_plan* plan, const void* A, int dtype, int64_t D, double* out,
+                    int native, void* stream);
+
+/* Second half of temx_zonal_mean for ncol-sharded use: B (all-reduced raw sums) -> out. A is
+ * only read when native != 0 is requested... it is not: pass the rank's plan; out [M][D] or
+ * this rank's [ncol][D]. */
+int temx_zonal_mean_from_sums(temx_plan* plan, const double* B, int64_t D, double* out,
+                              int native, void* stream);
+
+/* ---- TEM pipeline: replaces TEMDiagnostics.__init__ numerics + the ten diagnostics ----------
+ * (tem_diagnostics.py:491-611 and :615-797).  plev ascending (the front end flips,
+ * tem_diagnostics.py:372-382).  p_pa_host[nlev] = plev*100 (tem_diagnostics.py:385). */
+int temx_plan_set_tem(temx_plan* plan, int nlev, int64_t nt, const double* p_pa_host, double p0);
+
+/* stage 1: theta = T (p0/p)^kappa fused into the load (tem_diagnostics.py:498); raw sums
+ * B4[4][K][D] = Y0^T {u, v, theta, omega}   (first half of the 4+4 zonal means, :515-529). */
+int temx_tem_stage1(temx_plan* plan, const void* ua, const void* va, const void* ta,
+                    const void* wap, int dtype, double* B4, void* stream);
+
+/* stage 2: coefficients C = G^-1 B4, zonal means ub vb thetab wapb (Y0p C), then one sweep that
+ * reconstructs the native-grid means (Y0 C), forms the eddies x' = x - xbar (:517-529), the
+ * products u'v', u'w', v'theta' (:547-555) and projects them: B3[3][K][D] raw sums. */
+int temx_tem_stage2(temx_plan* plan, const void* ua, const void* va, const void* ta,
+                    const void* wap, int dtype, const double* B4, double* B3, void* stream);
+
+/* stage 3: flux zonal means (:549-557), the derivatives / psi / integral of
+ * _compute_derivatives (:574-599) and the ten diagnostics (:615-797) in one fused epilogue.
+ * results: [TEMX_NRESULTS][M][D] fp64.  zonal: NULL or [TEMX_NZONAL][M][D] fp64. */
+int temx_tem_stage3(temx_plan* plan, const double* B3, double* results, double* zonal,
+                    void* stream);
+
+/* all three stages with plan-owned B4/B3 (single-GPU / time-sharded use). */
+int temx_tem_run(temx_plan* plan, const void* ua, const void* va, const void* ta,
+                 const void* wap, int dtype, double* results, double* zonal, void* stream);
+
+/* lazily materialise the native-grid eddy fields (properties up vp thetap wapp upvp upwapp vptp,
+ * tem_diagnostics.py:420-433).  Needs the coefficients of a previous stage2/run on this plan.
+ * eddy_host_ptrs: TEMX_NEDDY device pointers ([ncol][D] fp64 each), NULL entries are skipped. */
+int temx_tem_eddy(temx_plan* plan, const void* ua, const void* va, const void* ta,
+                  const void* wap, int dtype, double* const* eddy_ptrs_host, void* stream);
+
+/* Synchronises the stream and reports whether any non-finite value reached the zonal sums
+ * since the last call (the reference raises on NaN input, sph_zonal_mean.py:219-221). */
+int temx_status(temx_plan* plan, int* nonfinite, void* stream);
+
+/* ---- measurement helpers (bench / tests only; not on the product path) ---------------------- */
+
+/* Deterministic synthetic fields of SURVEY section 8(d) written in place on the device:
+ * analytic part + 0.1 * N(0,1) noise from a counter hash (splitmix64 -> Box-Muller).
+ * lat/lon in degrees (device), plev_hpa (device). */
+int temx_synth_fields(int device, int64_t ncol, int nlev, int64_t nt, int64_t t0,
+                      const double* lat_deg, const double* lon_deg, const double* plev_hpa,
+                      int dtype, uint64_t seed, void* ua, void* va, void* ta, void* wap,
+                      void* stream);
+
+/* Bare v_mfma_f64_16x16x4_f64 issue-rate micro-benchmark: returns achieved TFLOP/s. */
+int temx_mfma_f64_peak(int device, int iters, double* tflops_out);
+
+/* Kernel-level timing hooks used by bench.py's roofline block: average duration (ms) of the
+ * dominant kernels over the launches since the last reset, measured with HIP events recorded
+ * on the launch stream. which: 0 = project sweep, 1 = eddy/flux sweep. */
+int temx_kernel_timing(temx_plan* plan, int enable);
+int temx_kernel_timing_read(temx_plan* plan, int which, double* avg_ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEMX_H */

@@ -1,0 +1,85 @@
+"""ctypes binding of libtemx.so (C ABI declared in include/temx.h).
+
+The library is the only compute back end: if it is missing or fails to load, importing the
+engine raises -- there is no CPU fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtemx.so")
+
+F64, F32 = 0, 1
+DEFER_FINALIZE = 1
+MAT_Y0, MAT_Y0P, MAT_GRAM, MAT_GINV, MAT_Y0INV = 0, 1, 2, 3, 4
+
+RESULT_NAMES = ("vtem", "omegatem", "wtem", "psitem", "epfy", "epfz", "epdiv",
+                "utendepfd", "utendvtem", "utendwtem")
+ZONAL_NAMES = ("ub", "vb", "thetab", "wapb", "upvpb", "upwappb", "vptpb", "dub_dp", "dthetab_dp",
+               "ubcoslat", "dubcoslat_dlat", "psi", "psicoslat", "dpsicoslat_dlat", "dpsi_dp",
+               "int_vbdp")
+EDDY_NAMES = ("up", "vp", "thetap", "wapp", "upvp", "upwapp", "vptp")
+
+ERRORS = {0: "TEMX_OK", -1: "TEMX_EINVAL", -2: "TEMX_EHIP", -3: "TEMX_ENOMEM", -4: "TEMX_ERANK",
+          -5: "TEMX_ESTATE", -6: "TEMX_EUNSUPPORTED"}
+
+# every symbol include/temx.h declares: (name, restype, argtypes)
+_vp, _i, _i64, _dp, _u64 = C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_double), C.c_uint64
+SIGNATURES = [
+    ("temx_version", _i, []),
+    ("temx_last_error", C.c_char_p, []),
+    ("temx_device_count", _i, []),
+    ("temx_plan_create", _i, [C.POINTER(_vp), _i, _i64, _i, _i, _dp, _dp, _i]),
+    ("temx_plan_finalize", _i, [_vp, _dp]),
+    ("temx_plan_set_weights", _i, [_vp, _dp]),
+    ("temx_plan_destroy", None, [_vp]),
+    ("temx_get_matrix", _i, [_vp, _i, _vp, _vp]),
+    ("temx_project", _i, [_vp, _vp, _i, _i64, _vp, _vp]),
+    ("temx_zonal_mean", _i, [_vp, _vp, _i, _i64, _vp, _i, _vp]),
+    ("temx_zonal_mean_from_sums", _i, [_vp, _vp, _i64, _vp, _i, _vp]),
+    ("temx_plan_set_tem", _i, [_vp, _i, _i64, _dp, C.c_double]),
+    ("temx_tem_stage1", _i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    ("temx_tem_stage2", _i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    ("temx_tem_stage3", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("temx_tem_run", _i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    ("temx_tem_eddy", _i, [_vp, _vp, _vp, _vp, _vp, _i, C.POINTER(_vp), _vp]),
+    ("temx_status", _i, [_vp, C.POINTER(_i), _vp]),
+    ("temx_synth_fields", _i, [_i, _i64, _i, _i64, _i64, _vp, _vp, _vp, _i, _u64, _vp, _vp, _vp, _vp, _vp]),
+    ("temx_mfma_f64_peak", _i, [_i, _i, _dp]),
+    ("temx_kernel_timing", _i, [_vp, _i]),
+    ("temx_kernel_timing_read", _i, [_vp, _i, _dp, C.POINTER(_i)]),
+]
+
+
+class TemxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (ERRORS.get(code, "TEMX_E?"), code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libtemx.so (once).  Raises RuntimeError when the HIP extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "pytemdiags_amd: HIP extension %s is missing. Build it with `make -C pytemdiags_amd/csrc` "
+            "or `python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SIGNATURES:
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise TemxError(rc, load().temx_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,789 @@
+// temx.hip -- host side of libtemx.so: plan, workspace, launch logic and the C ABI of
+// include/temx.h.  gfx950 only.  Build: see csrc/Makefile (hipcc --offload-arch=gfx950).
+#include "../../include/temx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace temx;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      return fail(e_ == hipErrorOutOfMemory ? TEMX_ENOMEM : TEMX_EHIP, "%s failed: %s",  \
+                  #expr, hipGetErrorString(e_));                                         \
+  } while (0)
+
+// physical constants of the reference (PyTEMDiags/constants.py:6-14)
+static const double kR = 287.058, kCp = 1004.64, kOm = 7.29212e-5;
+
+// ------------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return TEMX_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    hipError_t e = hipMalloc(&p, need);
+    if (e != hipSuccess) return fail(TEMX_ENOMEM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+    bytes = need;
+    return TEMX_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  double* d() const { return static_cast<double*>(p); }
+};
+
+struct Split {
+  int ndt = 0, nsplit = 0, grid = 0;
+};
+
+struct TimedLaunch {
+  hipEvent_t a, b;
+};
+
+struct temx_plan {
+  int device = 0, num_cu = 256;
+  int64_t N = 0, nchunk = 0;
+  int L = 0, K = 0, LT = 0, S = 0, K4 = 0, M = 0;
+  bool finalized = false;
+  DevBuf x, Y0, yproj, yrec, Y0p, G, Ginv, norm, flag;
+  std::vector<double> lat_out_deg;
+  // TEM configuration
+  bool tem = false;
+  int nlev = 0;
+  int64_t nt = 0, D = 0;
+  double p0 = 101325.0;
+  DevBuf p, pg, lg, coslat, fcor, colscale;
+  DevBuf B4, B3, C4, zb;
+  Split sp_proj4, sp_eddy;
+  // shared workspaces
+  DevBuf partial;
+  // operator-API workspace (any D)
+  DevBuf opB, opC;
+  // timing hooks
+  bool timing = false;
+  std::vector<TimedLaunch> timed[2];
+};
+
+static int upload(DevBuf& b, const void* src, size_t bytes) {
+  int rc = b.ensure(bytes);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+  return TEMX_OK;
+}
+
+// How to cut (d-tiles x chunk range) into wave-sized work so that `slots` workgroup slots
+// (CUs x resident workgroups) are evenly filled.  Smaller nsplit is preferred on near-ties
+// (fewer partial slabs to write and re-read).
+static Split choose_split(int64_t D, int64_t nchunk, int slots) {
+  Split s;
+  s.ndt = (int)((D + 15) / 16);
+  int64_t maxsplit = std::max<int64_t>(1, nchunk / 4);
+  maxsplit = std::min<int64_t>(maxsplit, std::max<int64_t>(1, (int64_t)16 * slots / s.ndt + 1));
+  maxsplit = std::min<int64_t>(maxsplit, 4096);
+  double best = -1.0;
+  int bestn = 1;
+  for (int n = 1; n <= maxsplit; ++n) {
+    const int64_t waves = (int64_t)s.ndt * n;
+    const int64_t nwg = (waves + 3) / 4;
+    const int64_t rounds = (nwg + slots - 1) / slots;
+    const double eff = (double)waves / (double)(rounds * slots * 4);
+    if (eff > best * 1.02) {
+      best = eff;
+      bestn = n;
+    }
+  }
+  s.nsplit = bestn;
+  const int64_t nwg = ((int64_t)s.ndt * s.nsplit + 3) / 4;
+  s.grid = (int)(((nwg + 7) / 8) * 8);
+  return s;
+}
+
+static void time_begin(temx_plan* pl, int which, hipStream_t st, TimedLaunch& tl) {
+  (void)which;
+  if (!pl->timing) return;
+  (void)hipEventCreate(&tl.a);
+  (void)hipEventCreate(&tl.b);
+  (void)hipEventRecord(tl.a, st);
+}
+static void time_end(temx_plan* pl, int which, hipStream_t st, TimedLaunch& tl) {
+  if (!pl->timing) return;
+  (void)hipEventRecord(tl.b, st);
+  pl->timed[which].push_back(tl);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NF>
+static int launch_project_t(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t D, const double* colscale,
+                            int sfield, double* partial, const Split& sp, hipStream_t st) {
+  dim3 grid(sp.grid), block(256);
+#define TEMX_LP(LTv)                                                                              \
+  hipLaunchKernelGGL((project_kernel<T, NF, LTv>), grid, block, 0, st, fp, pl->N, D, pl->K,       \
+                     pl->yproj.d(), pl->nchunk, colscale, sfield, partial, sp.nsplit, sp.ndt)
+  switch (pl->LT) {
+    case 1: TEMX_LP(1); break;
+    case 2: TEMX_LP(2); break;
+    case 3: TEMX_LP(3); break;
+    default: TEMX_LP(4); break;
+  }
+#undef TEMX_LP
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+template <int NF>
+static int launch_project(temx_plan* pl, const FieldPtrs<NF>& fp, int dtype, int64_t D,
+                          const double* colscale, int sfield, double* partial, const Split& sp,
+                          hipStream_t st) {
+  if (dtype == TEMX_F64) return launch_project_t<double, NF>(pl, fp, D, colscale, sfield, partial, sp, st);
+  if (dtype == TEMX_F32) return launch_project_t<float, NF>(pl, fp, D, colscale, sfield, partial, sp, st);
+  return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
+}
+
+static int launch_reduce(temx_plan* pl, const double* partial, int nsplit, int64_t n, double* B,
+                         hipStream_t st) {
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)blocks), dim3(256), 0, st, partial, nsplit, n, B,
+                     static_cast<int*>(pl->flag.p));
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+static int launch_solve(temx_plan* pl, const double* B, int NF, int64_t D, double* C, double* Xb,
+                        hipStream_t st) {
+  dim3 grid((unsigned)((D + 15) / 16), NF);
+  hipLaunchKernelGGL(solve_kernel, grid, dim3(256), 0, st, B, pl->K, pl->K4, pl->M, D, pl->Ginv.d(),
+                     pl->Y0p.d(), C, Xb);
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+template <typename T, int MODE>
+static int launch_eddy_t(temx_plan* pl, const FieldPtrs<4>& fp, double* partial, const Split& sp,
+                         const EddyOut& eo, hipStream_t st) {
+  dim3 grid(sp.grid), block(256);
+  const int SMAX_gen = 4 * pl->LT;
+#define TEMX_LE(LTv, SRECv, smax)                                                                     \
+  do {                                                                                                \
+    auto kern = eddy_kernel<T, LTv, SRECv, MODE>;                                                     \
+    const size_t lds = (size_t)4 * 4 * (smax)*64 * sizeof(double);                                    \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->N, pl->D, pl->K, pl->S, pl->yproj.d(),     \
+                       pl->yrec.d(), pl->nchunk, pl->colscale.d(), pl->C4.d(), partial, sp.nsplit,    \
+                       sp.ndt, eo);                                                                   \
+  } while (0)
+  if (pl->LT == 4 && pl->S == 13) {
+    TEMX_LE(4, 13, 13);
+  } else {
+    switch (pl->LT) {
+      case 1: TEMX_LE(1, 0, SMAX_gen); break;
+      case 2: TEMX_LE(2, 0, SMAX_gen); break;
+      case 3: TEMX_LE(3, 0, SMAX_gen); break;
+      default: TEMX_LE(4, 0, SMAX_gen); break;
+    }
+  }
+#undef TEMX_LE
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+static int launch_recon(temx_plan* pl, int64_t D, const double* C, double* out, hipStream_t st) {
+  Split sp = choose_split(D, pl->nchunk, pl->num_cu);
+  dim3 grid(sp.grid), block(256);
+#define TEMX_LR(LTv)                                                                                  \
+  do {                                                                                                \
+    auto kern = recon_kernel<LTv>;                                                                    \
+    const size_t lds = (size_t)4 * (4 * LTv) * 64 * sizeof(double);                                   \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, pl->N, D, pl->S, pl->yrec.d(), pl->nchunk, C, out, \
+                       sp.nsplit, sp.ndt);                                                            \
+  } while (0)
+  switch (pl->LT) {
+    case 1: TEMX_LR(1); break;
+    case 2: TEMX_LR(2); break;
+    case 3: TEMX_LR(3); break;
+    default: TEMX_LR(4); break;
+  }
+#undef TEMX_LR
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host linear algebra: Cholesky inverse of the K x K Gram matrix (K <= 64)
+// ------------------------------------------------------------------------------------------------
+static int spd_inverse(const double* G, int K, double* Ginv) {
+  std::vector<long double> Lm((size_t)K * K, 0.0L), Li((size_t)K * K, 0.0L);
+  for (int i = 0; i < K; ++i) {
+    for (int j = 0; j <= i; ++j) {
+      long double s = G[i * K + j];
+      for (int k = 0; k < j; ++k) s -= Lm[i * K + k] * Lm[j * K + k];
+      if (i == j) {
+        if (!(s > 0.0L) || !(s <= 1e300L)) return -1;
+        Lm[i * K + i] = sqrtl(s);
+      } else {
+        Lm[i * K + j] = s / Lm[j * K + j];
+      }
+    }
+  }
+  // a rank-deficient Gram shows up as a tiny pivot relative to the diagonal
+  for (int i = 0; i < K; ++i)
+    if (Lm[i * K + i] * Lm[i * K + i] < 1e-13L * (long double)G[i * K + i]) return -1;
+  for (int c = 0; c < K; ++c) {  // Li = L^-1 by forward substitution
+    for (int i = c; i < K; ++i) {
+      long double s = (i == c) ? 1.0L : 0.0L;
+      for (int k = c; k < i; ++k) s -= Lm[i * K + k] * Li[k * K + c];
+      Li[i * K + c] = s / Lm[i * K + i];
+    }
+  }
+  for (int i = 0; i < K; ++i)
+    for (int j = 0; j < K; ++j) {
+      long double s = 0.0L;
+      for (int k = std::max(i, j); k < K; ++k) s += Li[k * K + i] * Li[k * K + j];
+      Ginv[i * K + j] = (double)s;
+    }
+  return 0;
+}
+
+// np.gradient(f, x) coefficient table out[i] = a f[i-1] + b f[i] + c f[i+1], edge_order = 1
+// (tem_util.py:154, 192).  numpy switches to the uniform formula only when diff(x) is bit-uniform.
+static void gradient_table(const std::vector<double>& x, std::vector<double>& tab) {
+  const int n = (int)x.size();
+  tab.assign((size_t)n * 3, 0.0);
+  std::vector<double> dx(n - 1);
+  for (int i = 0; i + 1 < n; ++i) dx[i] = x[i + 1] - x[i];
+  bool uniform = true;
+  for (int i = 1; i + 1 < n; ++i) uniform = uniform && (dx[i] == dx[0]);
+  for (int i = 1; i + 1 < n; ++i) {
+    if (uniform) {
+      tab[i * 3 + 0] = -1.0 / (2.0 * dx[0]);
+      tab[i * 3 + 2] = 1.0 / (2.0 * dx[0]);
+    } else {
+      const double d1 = dx[i - 1], d2 = dx[i];
+      tab[i * 3 + 0] = -(d2) / (d1 * (d1 + d2));
+      tab[i * 3 + 1] = (d2 - d1) / (d1 * d2);
+      tab[i * 3 + 2] = d1 / (d2 * (d1 + d2));
+    }
+  }
+  tab[0 * 3 + 1] = -1.0 / dx[0];
+  tab[0 * 3 + 2] = 1.0 / dx[0];
+  tab[(n - 1) * 3 + 0] = -1.0 / dx[n - 2];
+  tab[(n - 1) * 3 + 1] = 1.0 / dx[n - 2];
+}
+
+static inline hipStream_t S_(void* s) { return static_cast<hipStream_t>(s); }
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int temx_version(void) { return 100; }
+
+const char* temx_last_error(void) { return g_err.c_str(); }
+
+int temx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void temx_plan_destroy(temx_plan* pl) {
+  if (!pl) return;
+  (void)hipSetDevice(pl->device);
+  DevBuf* bufs[] = {&pl->x, &pl->Y0, &pl->yproj, &pl->yrec, &pl->Y0p, &pl->G, &pl->Ginv, &pl->norm,
+                    &pl->flag, &pl->p, &pl->pg, &pl->lg, &pl->coslat, &pl->fcor, &pl->colscale,
+                    &pl->B4, &pl->B3, &pl->C4, &pl->zb, &pl->partial, &pl->opB, &pl->opC};
+  for (DevBuf* b : bufs) b->release();
+  for (int w = 0; w < 2; ++w)
+    for (auto& tl : pl->timed[w]) {
+      (void)hipEventDestroy(tl.a);
+      (void)hipEventDestroy(tl.b);
+    }
+  delete pl;
+}
+
+static int build_basis(temx_plan* pl, const double* rowscale_dev) {
+  const int64_t npad = pl->nchunk * 16;
+  hipLaunchKernelGGL(basis_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, 0, pl->x.d(), pl->N,
+                     pl->nchunk, pl->K, pl->LT, pl->S, pl->norm.d(), rowscale_dev, pl->Y0.d(),
+                     pl->yproj.d(), pl->yrec.d());
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
+                     const double* lat_deg_host, const double* lat_out_deg_host, int flags) {
+  if (!out || !lat_deg_host || !lat_out_deg_host) return fail(TEMX_EINVAL, "null argument");
+  *out = nullptr;
+  if (ncol < 1 || M < 1 || L < 0) return fail(TEMX_EINVAL, "ncol, M must be >= 1 and L >= 0");
+  if (L > 63) return fail(TEMX_EUNSUPPORTED, "L = %d: this version supports L <= 63", L);
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(TEMX_EHIP, "device %d not available (%d visible)", device, ndev);
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(TEMX_EUNSUPPORTED, "libtemx is built for gfx950 (MI355X); device is %s", prop.gcnArchName);
+
+  temx_plan* pl = new temx_plan();
+  pl->device = device;
+  pl->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  pl->N = ncol;
+  pl->nchunk = (ncol + 15) / 16;
+  pl->L = L;
+  pl->K = L + 1;
+  pl->LT = (pl->K + 15) / 16;
+  pl->S = (pl->K + 3) / 4;
+  pl->K4 = 4 * pl->S;
+  pl->M = M;
+  pl->lat_out_deg.assign(lat_out_deg_host, lat_out_deg_host + M);
+  int rc = TEMX_OK;
+  auto bail = [&](int code) {
+    temx_plan_destroy(pl);
+    return code;
+  };
+
+  // x = cos(colat), colat = deg2rad(90 - lat)   (sph_zonal_mean.py:361)
+  const double d2r = M_PI / 180.0;
+  std::vector<double> xs((size_t)std::max<int64_t>(ncol, M));
+  for (int64_t i = 0; i < ncol; ++i) xs[i] = std::cos((90.0 - lat_deg_host[i]) * d2r);
+  if ((rc = upload(pl->x, xs.data(), (size_t)ncol * 8))) return bail(rc);
+  std::vector<double> norm(64, 0.0);
+  for (int l = 0; l < pl->K; ++l) norm[l] = std::sqrt((2.0 * l + 1.0) / (4.0 * M_PI));
+  if ((rc = upload(pl->norm, norm.data(), 64 * 8))) return bail(rc);
+  int zero = 0;
+  if ((rc = upload(pl->flag, &zero, sizeof(int)))) return bail(rc);
+
+  if ((rc = pl->Y0.ensure((size_t)ncol * pl->K * 8))) return bail(rc);
+  if ((rc = pl->yproj.ensure((size_t)pl->nchunk * pl->LT * 4 * 64 * 8))) return bail(rc);
+  if ((rc = pl->yrec.ensure((size_t)pl->nchunk * pl->S * 64 * 8))) return bail(rc);
+  if ((rc = build_basis(pl, nullptr))) return bail(rc);
+
+  // Y0p on the output latitudes (sph_zonal_mean.py:367-370): same kernel, canonical copy only
+  {
+    DevBuf xo;
+    for (int m = 0; m < M; ++m) xs[m] = std::cos((90.0 - lat_out_deg_host[m]) * d2r);
+    if ((rc = upload(xo, xs.data(), (size_t)M * 8))) return bail(rc);
+    if ((rc = pl->Y0p.ensure((size_t)M * pl->K * 8))) {
+      xo.release();
+      return bail(rc);
+    }
+    const int64_t mch = (M + 15) / 16;
+    hipLaunchKernelGGL(basis_kernel, dim3((unsigned)((mch * 16 + 255) / 256)), dim3(256), 0, 0, xo.d(),
+                       (int64_t)M, mch, pl->K, pl->LT, pl->S, pl->norm.d(), (const double*)nullptr,
+                       pl->Y0p.d(), (double*)nullptr, (double*)nullptr);
+    hipError_t e = hipDeviceSynchronize();
+    xo.release();
+    if (e != hipSuccess) return bail(fail(TEMX_EHIP, "basis kernel failed: %s", hipGetErrorString(e)));
+  }
+
+  // local Gram G = Y0^T Y0 through the projection sweep itself (A = Y0, D = K)
+  {
+    if ((rc = pl->G.ensure((size_t)pl->K * pl->K * 8))) return bail(rc);
+    if ((rc = pl->Ginv.ensure((size_t)pl->K * pl->K * 8))) return bail(rc);
+    Split sp = choose_split(pl->K, pl->nchunk, 2 * pl->num_cu);
+    if ((rc = pl->partial.ensure((size_t)sp.nsplit * pl->K * pl->K * 8))) return bail(rc);
+    FieldPtrs<1> fp;
+    fp.p[0] = pl->Y0.p;
+    if ((rc = launch_project<1>(pl, fp, TEMX_F64, pl->K, nullptr, -1, pl->partial.d(), sp, 0))) return bail(rc);
+    if ((rc = launch_reduce(pl, pl->partial.d(), sp.nsplit, (int64_t)pl->K * pl->K, pl->G.d(), 0))) return bail(rc);
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return bail(fail(TEMX_EHIP, "gram kernel failed: %s", hipGetErrorString(e)));
+  }
+  if (!(flags & TEMX_DEFER_FINALIZE)) {
+    if ((rc = temx_plan_finalize(pl, nullptr))) return bail(rc);
+  }
+  *out = pl;
+  return TEMX_OK;
+}
+
+int temx_plan_finalize(temx_plan* pl, const double* G_host) {
+  if (!pl) return fail(TEMX_EINVAL, "null plan");
+  HIPCHK(hipSetDevice(pl->device));
+  const int K = pl->K;
+  std::vector<double> G((size_t)K * K), Gi((size_t)K * K);
+  if (G_host) {
+    std::copy(G_host, G_host + (size_t)K * K, G.begin());
+    HIPCHK(hipMemcpy(pl->G.p, G.data(), G.size() * 8, hipMemcpyHostToDevice));
+  } else {
+    HIPCHK(hipMemcpy(G.data(), pl->G.p, G.size() * 8, hipMemcpyDeviceToHost));
+  }
+  for (double v : G)
+    if (!std::isfinite(v)) return fail(TEMX_EINVAL, "Gram matrix is not finite (NaN latitudes?)");
+  if (spd_inverse(G.data(), K, Gi.data()) != 0)
+    return fail(TEMX_ERANK, "Y0^T Y0 is not positive definite: Y0 (N=%lld, K=%d) is rank deficient "
+                "(fewer distinct latitudes than harmonics?)", (long long)pl->N, K);
+  HIPCHK(hipMemcpy(pl->Ginv.p, Gi.data(), Gi.size() * 8, hipMemcpyHostToDevice));
+  int zero = 0;
+  HIPCHK(hipMemcpy(pl->flag.p, &zero, sizeof(int), hipMemcpyHostToDevice));
+  pl->finalized = true;
+  return TEMX_OK;
+}
+
+int temx_plan_set_weights(temx_plan* pl, const double* w_host) {
+  if (!pl || !w_host) return fail(TEMX_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(pl->device));
+  // Y0inv = Y0^T diag(4 pi w)  (sph_zonal_mean.py:181, 385): scale the projection operand rows,
+  // and make the "Gram inverse" the identity.
+  std::vector<double> w((size_t)pl->N);
+  for (int64_t i = 0; i < pl->N; ++i) w[i] = w_host[i] * 4.0 * M_PI;
+  DevBuf wd;
+  int rc = upload(wd, w.data(), w.size() * 8);
+  if (rc) return rc;
+  rc = build_basis(pl, wd.d());
+  hipError_t e = hipDeviceSynchronize();
+  wd.release();
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(TEMX_EHIP, "basis kernel failed: %s", hipGetErrorString(e));
+  std::vector<double> I((size_t)pl->K * pl->K, 0.0);
+  for (int k = 0; k < pl->K; ++k) I[(size_t)k * pl->K + k] = 1.0;
+  HIPCHK(hipMemcpy(pl->Ginv.p, I.data(), I.size() * 8, hipMemcpyHostToDevice));
+  pl->finalized = true;
+  return TEMX_OK;
+}
+
+int temx_get_matrix(temx_plan* pl, int which, double* dst, void* stream) {
+  if (!pl || !dst) return fail(TEMX_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(pl->device));
+  hipStream_t st = S_(stream);
+  const size_t KK = (size_t)pl->K * pl->K * 8;
+  switch (which) {
+    case TEMX_MAT_Y0:
+      HIPCHK(hipMemcpyAsync(dst, pl->Y0.p, (size_t)pl->N * pl->K * 8, hipMemcpyDeviceToDevice, st));
+      return TEMX_OK;
+    case TEMX_MAT_Y0P:
+      HIPCHK(hipMemcpyAsync(dst, pl->Y0p.p, (size_t)pl->M * pl->K * 8, hipMemcpyDeviceToDevice, st));
+      return TEMX_OK;
+    case TEMX_MAT_GRAM:
+      HIPCHK(hipMemcpyAsync(dst, pl->G.p, KK, hipMemcpyDeviceToDevice, st));
+      return TEMX_OK;
+    case TEMX_MAT_GINV:
+      if (!pl->finalized) return fail(TEMX_ESTATE, "plan not finalised");
+      HIPCHK(hipMemcpyAsync(dst, pl->Ginv.p, KK, hipMemcpyDeviceToDevice, st));
+      return TEMX_OK;
+    case TEMX_MAT_Y0INV:
+      if (!pl->finalized) return fail(TEMX_ESTATE, "plan not finalised");
+      hipLaunchKernelGGL(y0inv_kernel, dim3((unsigned)((pl->N + 255) / 256)), dim3(256), 0, st, pl->Y0.d(),
+                         pl->Ginv.d(), pl->N, pl->K, dst);
+      HIPCHK(hipGetLastError());
+      return TEMX_OK;
+    default:
+      return fail(TEMX_EINVAL, "unknown matrix id %d", which);
+  }
+}
+
+// ---- operator API --------------------------------------------------------------------------------
+int temx_project(temx_plan* pl, const void* A, int dtype, int64_t D, double* B, void* stream) {
+  if (!pl || !A || !B) return fail(TEMX_EINVAL, "null argument");
+  if (D < 1) return fail(TEMX_EINVAL, "D must be >= 1");
+  HIPCHK(hipSetDevice(pl->device));
+  Split sp = choose_split(D, pl->nchunk, 2 * pl->num_cu);
+  int rc = pl->partial.ensure((size_t)sp.nsplit * pl->K * D * 8);
+  if (rc) return rc;
+  FieldPtrs<1> fp;
+  fp.p[0] = A;
+  if ((rc = launch_project<1>(pl, fp, dtype, D, nullptr, -1, pl->partial.d(), sp, S_(stream)))) return rc;
+  return launch_reduce(pl, pl->partial.d(), sp.nsplit, (int64_t)pl->K * D, B, S_(stream));
+}
+
+int temx_zonal_mean_from_sums(temx_plan* pl, const double* B, int64_t D, double* out, int native,
+                              void* stream) {
+  if (!pl || !B || !out) return fail(TEMX_EINVAL, "null argument");
+  if (!pl->finalized) return fail(TEMX_ESTATE, "plan not finalised");
+  HIPCHK(hipSetDevice(pl->device));
+  int rc;
+  if (!native) return launch_solve(pl, B, 1, D, nullptr, out, S_(stream));
+  if ((rc = pl->opC.ensure((size_t)pl->K4 * D * 8))) return rc;
+  if ((rc = launch_solve(pl, B, 1, D, pl->opC.d(), nullptr, S_(stream)))) return rc;
+  return launch_recon(pl, D, pl->opC.d(), out, S_(stream));
+}
+
+int temx_zonal_mean(temx_plan* pl, const void* A, int dtype, int64_t D, double* out, int native,
+                    void* stream) {
+  if (!pl || !A || !out) return fail(TEMX_EINVAL, "null argument");
+  if (!pl->finalized) return fail(TEMX_ESTATE, "plan not finalised");
+  int rc = pl->opB.ensure((size_t)pl->K * std::max<int64_t>(D, 1) * 8);
+  if (rc) return rc;
+  if ((rc = temx_project(pl, A, dtype, D, pl->opB.d(), stream))) return rc;
+  return temx_zonal_mean_from_sums(pl, pl->opB.d(), D, out, native, stream);
+}
+
+// ---- TEM pipeline --------------------------------------------------------------------------------
+int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_host, double p0) {
+  if (!pl || !p_pa_host) return fail(TEMX_EINVAL, "null argument");
+  if (nlev < 2 || nt < 1) return fail(TEMX_EINVAL, "need nlev >= 2 and nt >= 1");
+  if (pl->M < 2) return fail(TEMX_EINVAL, "need at least 2 zonal-mean latitudes");
+  HIPCHK(hipSetDevice(pl->device));
+  pl->nlev = nlev;
+  pl->nt = nt;
+  pl->D = (int64_t)nlev * nt;
+  pl->p0 = p0;
+  const int M = pl->M;
+  const int64_t D = pl->D;
+  std::vector<double> p(p_pa_host, p_pa_host + nlev), tab;
+  for (int j = 1; j < nlev; ++j)
+    if (!(p[j] > p[j - 1])) return fail(TEMX_EINVAL, "pressure must be strictly ascending (front end flips)");
+  int rc;
+  if ((rc = upload(pl->p, p.data(), (size_t)nlev * 8))) return rc;
+  gradient_table(p, tab);
+  if ((rc = upload(pl->pg, tab.data(), tab.size() * 8))) return rc;
+  // latitude tables: f and cos(lat) use lat*pi/180 (tem_diagnostics.py:401-402), the gradient
+  // uses np.deg2rad(lat) = lat*(pi/180) (:586)
+  std::vector<double> latr(M), cosl(M), fc(M);
+  for (int m = 0; m < M; ++m) {
+    const double lat = pl->lat_out_deg[m];
+    latr[m] = lat * (M_PI / 180.0);
+    cosl[m] = std::cos(lat * M_PI / 180.0);
+    fc[m] = 2 * kOm * std::sin(lat * M_PI / 180.0);
+  }
+  gradient_table(latr, tab);
+  if ((rc = upload(pl->lg, tab.data(), tab.size() * 8))) return rc;
+  if ((rc = upload(pl->coslat, cosl.data(), (size_t)M * 8))) return rc;
+  if ((rc = upload(pl->fcor, fc.data(), (size_t)M * 8))) return rc;
+  // theta = T (p0/p)^k, k = R/Cp  (tem_diagnostics.py:498, constants.py:12): per-column scale
+  std::vector<double> cs((size_t)D);
+  const double kap = kR / kCp;
+  for (int j = 0; j < nlev; ++j) {
+    const double s = std::pow(p0 / p[j], kap);
+    for (int64_t t = 0; t < nt; ++t) cs[(size_t)j * nt + t] = s;
+  }
+  if ((rc = upload(pl->colscale, cs.data(), cs.size() * 8))) return rc;
+
+  pl->sp_proj4 = choose_split(D, pl->nchunk, 2 * pl->num_cu);
+  pl->sp_eddy = choose_split(D, pl->nchunk, pl->num_cu);
+  const size_t need = (size_t)std::max(pl->sp_proj4.nsplit * 4, pl->sp_eddy.nsplit * 3) * pl->K * D * 8;
+  if ((rc = pl->partial.ensure(need))) return rc;
+  if ((rc = pl->B4.ensure((size_t)4 * pl->K * D * 8))) return rc;
+  if ((rc = pl->B3.ensure((size_t)3 * pl->K * D * 8))) return rc;
+  if ((rc = pl->C4.ensure((size_t)4 * pl->K4 * D * 8))) return rc;
+  if ((rc = pl->zb.ensure((size_t)8 * M * D * 8))) return rc;
+  pl->tem = true;
+  return TEMX_OK;
+}
+
+static int tem_ready(temx_plan* pl) {
+  if (!pl) return fail(TEMX_EINVAL, "null plan");
+  if (!pl->finalized) return fail(TEMX_ESTATE, "plan not finalised");
+  if (!pl->tem) return fail(TEMX_ESTATE, "temx_plan_set_tem has not been called");
+  return TEMX_OK;
+}
+
+int temx_tem_stage1(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap,
+                    int dtype, double* B4, void* stream) {
+  int rc = tem_ready(pl);
+  if (rc) return rc;
+  if (!ua || !va || !ta || !wap || !B4) return fail(TEMX_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(pl->device));
+  hipStream_t st = S_(stream);
+  FieldPtrs<4> fp;
+  fp.p[0] = ua; fp.p[1] = va; fp.p[2] = ta; fp.p[3] = wap;
+  TimedLaunch tl{};
+  time_begin(pl, 0, st, tl);
+  rc = launch_project<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->partial.d(), pl->sp_proj4, st);
+  time_end(pl, 0, st, tl);
+  if (rc) return rc;
+  return launch_reduce(pl, pl->partial.d(), pl->sp_proj4.nsplit, (int64_t)4 * pl->K * pl->D, B4, st);
+}
+
+static int run_eddy(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap,
+                    int dtype, double* partial, const EddyOut* eo, hipStream_t st) {
+  FieldPtrs<4> fp;
+  fp.p[0] = ua; fp.p[1] = va; fp.p[2] = ta; fp.p[3] = wap;
+  EddyOut none{};
+  if (dtype == TEMX_F64) {
+    return eo ? launch_eddy_t<double, 1>(pl, fp, partial, pl->sp_eddy, *eo, st)
+              : launch_eddy_t<double, 0>(pl, fp, partial, pl->sp_eddy, none, st);
+  }
+  if (dtype == TEMX_F32) {
+    return eo ? launch_eddy_t<float, 1>(pl, fp, partial, pl->sp_eddy, *eo, st)
+              : launch_eddy_t<float, 0>(pl, fp, partial, pl->sp_eddy, none, st);
+  }
+  return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
+}
+
+int temx_tem_stage2(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap,
+                    int dtype, const double* B4, double* B3, void* stream) {
+  int rc = tem_ready(pl);
+  if (rc) return rc;
+  if (!ua || !va || !ta || !wap || !B4 || !B3) return fail(TEMX_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(pl->device));
+  hipStream_t st = S_(stream);
+  // C = G^-1 B4 and the four zonal means ub vb thetab wapb -> zb[0..3]
+  if ((rc = launch_solve(pl, B4, 4, pl->D, pl->C4.d(), pl->zb.d(), st))) return rc;
+  TimedLaunch tl{};
+  time_begin(pl, 1, st, tl);
+  rc = run_eddy(pl, ua, va, ta, wap, dtype, pl->partial.d(), nullptr, st);
+  time_end(pl, 1, st, tl);
+  if (rc) return rc;
+  return launch_reduce(pl, pl->partial.d(), pl->sp_eddy.nsplit, (int64_t)3 * pl->K * pl->D, B3, st);
+}
+
+int temx_tem_stage3(temx_plan* pl, const double* B3, double* results, double* zonal, void* stream) {
+  int rc = tem_ready(pl);
+  if (rc) return rc;
+  if (!B3 || !results) return fail(TEMX_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(pl->device));
+  hipStream_t st = S_(stream);
+  const int64_t MD = (int64_t)pl->M * pl->D;
+  // flux zonal means upvpb upwappb vptpb -> zb[4..6]
+  if ((rc = launch_solve(pl, B3, 3, pl->D, nullptr, pl->zb.d() + 4 * MD, st))) return rc;
+  // int_vbdp -> zb[7]
+  const int64_t ncols = (int64_t)pl->M * pl->nt;
+  hipLaunchKernelGGL(pint_scan_kernel, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st, pl->zb.d() + 1 * MD,
+                     pl->p.d(), pl->M, pl->nlev, pl->nt, pl->zb.d() + 7 * MD);
+  HIPCHK(hipGetLastError());
+  EpiTables tb{pl->p.d(), pl->pg.d(), pl->lg.d(), pl->coslat.d(), pl->fcor.d()};
+  hipLaunchKernelGGL(tem_epilogue_kernel, dim3((unsigned)((MD + 255) / 256)), dim3(256), 0, st, pl->zb.d(),
+                     pl->M, pl->nlev, pl->nt, tb, pl->p0, results, zonal);
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+int temx_tem_run(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap,
+                 int dtype, double* results, double* zonal, void* stream) {
+  int rc = tem_ready(pl);
+  if (rc) return rc;
+  if ((rc = temx_tem_stage1(pl, ua, va, ta, wap, dtype, pl->B4.d(), stream))) return rc;
+  if ((rc = temx_tem_stage2(pl, ua, va, ta, wap, dtype, pl->B4.d(), pl->B3.d(), stream))) return rc;
+  return temx_tem_stage3(pl, pl->B3.d(), results, zonal, stream);
+}
+
+int temx_tem_eddy(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap,
+                  int dtype, double* const* eddy_ptrs_host, void* stream) {
+  int rc = tem_ready(pl);
+  if (rc) return rc;
+  if (!ua || !va || !ta || !wap || !eddy_ptrs_host) return fail(TEMX_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(pl->device));
+  EddyOut eo;
+  for (int i = 0; i < TEMX_NEDDY; ++i) eo.p[i] = eddy_ptrs_host[i];
+  return run_eddy(pl, ua, va, ta, wap, dtype, nullptr, &eo, S_(stream));
+}
+
+int temx_status(temx_plan* pl, int* nonfinite, void* stream) {
+  if (!pl || !nonfinite) return fail(TEMX_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(pl->device));
+  HIPCHK(hipStreamSynchronize(S_(stream)));
+  int f = 0;
+  HIPCHK(hipMemcpy(&f, pl->flag.p, sizeof(int), hipMemcpyDeviceToHost));
+  *nonfinite = f;
+  if (f) {
+    int zero = 0;
+    HIPCHK(hipMemcpy(pl->flag.p, &zero, sizeof(int), hipMemcpyHostToDevice));
+  }
+  return TEMX_OK;
+}
+
+// ---- measurement helpers -------------------------------------------------------------------------
+int temx_synth_fields(int device, int64_t ncol, int nlev, int64_t nt, int64_t t0, const double* lat_deg,
+                      const double* lon_deg, const double* plev_hpa, int dtype, uint64_t seed, void* ua,
+                      void* va, void* ta, void* wap, void* stream) {
+  if (!lat_deg || !lon_deg || !plev_hpa || !ua || !va || !ta || !wap) return fail(TEMX_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(device));
+  dim3 grid(256 * 16), block(256);
+  if (dtype == TEMX_F64) {
+    hipLaunchKernelGGL(synth_kernel<double>, grid, block, 0, S_(stream), ncol, nlev, nt, t0, lat_deg, lon_deg,
+                       plev_hpa, seed, (double*)ua, (double*)va, (double*)ta, (double*)wap);
+  } else if (dtype == TEMX_F32) {
+    hipLaunchKernelGGL(synth_kernel<float>, grid, block, 0, S_(stream), ncol, nlev, nt, t0, lat_deg, lon_deg,
+                       plev_hpa, seed, (float*)ua, (float*)va, (float*)ta, (float*)wap);
+  } else {
+    return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
+  }
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+int temx_mfma_f64_peak(int device, int iters, double* tflops_out) {
+  if (!tflops_out || iters < 1) return fail(TEMX_EINVAL, "bad argument");
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  double* sink = nullptr;
+  HIPCHK(hipMalloc(&sink, 8));
+  const int blocks = prop.multiProcessorCount * 2;  // 8 waves per CU, 2 per SIMD
+  hipEvent_t a, b;
+  HIPCHK(hipEventCreate(&a));
+  HIPCHK(hipEventCreate(&b));
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, iters, sink);  // warm-up
+  HIPCHK(hipEventRecord(a, 0));
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, iters, sink);
+  HIPCHK(hipEventRecord(b, 0));
+  HIPCHK(hipEventSynchronize(b));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, a, b));
+  const double flops = (double)blocks * 4.0 * iters * 4.0 * 2048.0;
+  *tflops_out = flops / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  (void)hipFree(sink);
+  return TEMX_OK;
+}
+
+int temx_kernel_timing(temx_plan* pl, int enable) {
+  if (!pl) return fail(TEMX_EINVAL, "null plan");
+  pl->timing = enable != 0;
+  for (int w = 0; w < 2; ++w) {
+    for (auto& tl : pl->timed[w]) {
+      (void)hipEventDestroy(tl.a);
+      (void)hipEventDestroy(tl.b);
+    }
+    pl->timed[w].clear();
+  }
+  return TEMX_OK;
+}
+
+int temx_kernel_timing_read(temx_plan* pl, int which, double* avg_ms, int* launches) {
+  if (!pl || !avg_ms || !launches || which < 0 || which > 1) return fail(TEMX_EINVAL, "bad argument");
+  HIPCHK(hipSetDevice(pl->device));
+  double tot = 0.0;
+  int n = 0;
+  for (auto& tl : pl->timed[which]) {
+    HIPCHK(hipEventSynchronize(tl.b));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, tl.a, tl.b));
+    tot += ms;
+    ++n;
+  }
+  *avg_ms = n ? tot / n : 0.0;
+  *launches = n;
+  return TEMX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,220 @@
+"""Thin object wrapper over the C ABI (include/temx.h).  PyTorch-ROCm tensors are only the
+device container: every number is produced by the HIP kernels in csrc/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+_DT = {torch.float64: _lib.F64, torch.float32: _lib.F32}
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _dbl(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Plan:
+    """One plan per (device, native grid, output latitudes, L).  See include/temx.h."""
+
+    def __init__(self, lat_deg, lat_out_deg, L, device=0, defer_finalize=False):
+        self._h = C.c_void_p()
+        self.lib = _lib.load()
+        if isinstance(device, torch.device):
+            device = device.index or 0
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        lat, plat = _dbl(lat_deg)
+        lat_out, plat_out = _dbl(lat_out_deg)
+        self.N, self.M, self.L, self.K = int(lat.size), int(lat_out.size), int(L), int(L) + 1
+        self.lat_out = lat_out
+        self.nlev = self.nt = self.D = None
+        check(self.lib.temx_plan_create(C.byref(self._h), self.device_index, self.N, self.L, self.M,
+                                        plat, plat_out, _lib.DEFER_FINALIZE if defer_finalize else 0))
+
+    # ---- lifetime ----
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.temx_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _field(self, A, D=None):
+        if not isinstance(A, torch.Tensor):
+            raise TypeError("device tensors expected")
+        if A.device != self.device:
+            raise ValueError("tensor on %s, plan on %s" % (A.device, self.device))
+        if A.dtype not in _DT:
+            raise TypeError("dtype must be float64 or float32, got %s" % A.dtype)
+        if A.shape[0] != self.N:
+            raise ValueError("leading dimension must be ncol = %d" % self.N)
+        A = A.contiguous()
+        if D is not None and A.numel() != self.N * D:
+            raise ValueError("field has %d elements, expected %d x %d" % (A.numel(), self.N, D))
+        return A
+
+    # ---- plan pieces ----
+    def finalize(self, G=None):
+        if G is None:
+            check(self.lib.temx_plan_finalize(self._h, None))
+        else:
+            g, pg = _dbl(G)
+            assert g.shape == (self.K, self.K)
+            check(self.lib.temx_plan_finalize(self._h, pg))
+
+    def set_weights(self, weights):
+        w, pw = _dbl(weights)
+        assert w.size == self.N
+        check(self.lib.temx_plan_set_weights(self._h, pw))
+
+    def matrix(self, which):
+        shape = {_lib.MAT_Y0: (self.N, self.K), _lib.MAT_Y0P: (self.M, self.K),
+                 _lib.MAT_GRAM: (self.K, self.K), _lib.MAT_GINV: (self.K, self.K),
+                 _lib.MAT_Y0INV: (self.K, self.N)}[which]
+        out = torch.empty(shape, dtype=torch.float64, device=self.device)
+        check(self.lib.temx_get_matrix(self._h, which, _ptr(out), self._stream()))
+        return out
+
+    # ---- operator API ----
+    def project(self, A):
+        A = self._field(A)
+        D = A.numel() // self.N
+        B = torch.empty((self.K, D), dtype=torch.float64, device=self.device)
+        check(self.lib.temx_project(self._h, _ptr(A), _DT[A.dtype], D, _ptr(B), self._stream()))
+        return B
+
+    def zonal_mean(self, A, native=False):
+        A = self._field(A)
+        D = A.numel() // self.N
+        out = torch.empty((self.N if native else self.M,) + tuple(A.shape[1:]), dtype=torch.float64,
+                          device=self.device)
+        check(self.lib.temx_zonal_mean(self._h, _ptr(A), _DT[A.dtype], D, _ptr(out), 1 if native else 0,
+                                       self._stream()))
+        return out
+
+    def zonal_mean_from_sums(self, B, trailing_shape, native=False):
+        D = int(B.shape[1])
+        out = torch.empty((self.N if native else self.M,) + tuple(trailing_shape), dtype=torch.float64,
+                          device=self.device)
+        check(self.lib.temx_zonal_mean_from_sums(self._h, _ptr(B.contiguous()), D, _ptr(out),
+                                                 1 if native else 0, self._stream()))
+        return out
+
+    # ---- TEM pipeline ----
+    def set_tem(self, nlev, nt, p_pa, p0=101325.0):
+        p, pp = _dbl(p_pa)
+        assert p.size == nlev
+        check(self.lib.temx_plan_set_tem(self._h, int(nlev), int(nt), pp, float(p0)))
+        self.nlev, self.nt, self.D = int(nlev), int(nt), int(nlev) * int(nt)
+
+    def _four(self, ua, va, ta, wap):
+        if self.D is None:
+            raise _lib.TemxError(-5, "temx_plan_set_tem has not been called")
+        fs = [self._field(x, self.D) for x in (ua, va, ta, wap)]
+        if len({f.dtype for f in fs}) != 1:
+            raise TypeError("ua, va, ta, wap must share one dtype")
+        return fs, _DT[fs[0].dtype]
+
+    def _alloc_results(self, want_zonal):
+        res = torch.empty((len(_lib.RESULT_NAMES), self.M, self.nlev, self.nt), dtype=torch.float64,
+                          device=self.device)
+        zon = None
+        if want_zonal:
+            zon = torch.empty((len(_lib.ZONAL_NAMES), self.M, self.nlev, self.nt), dtype=torch.float64,
+                              device=self.device)
+        return res, zon
+
+    def tem_run(self, ua, va, ta, wap, want_zonal=False, out=None):
+        (u, v, t, w), dt = self._four(ua, va, ta, wap)
+        res, zon = out if out is not None else self._alloc_results(want_zonal)
+        check(self.lib.temx_tem_run(self._h, _ptr(u), _ptr(v), _ptr(t), _ptr(w), dt, _ptr(res),
+                                    _ptr(zon) if zon is not None else None, self._stream()))
+        return res, zon
+
+    def tem_stage1(self, ua, va, ta, wap):
+        (u, v, t, w), dt = self._four(ua, va, ta, wap)
+        B4 = torch.empty((4, self.K, self.D), dtype=torch.float64, device=self.device)
+        check(self.lib.temx_tem_stage1(self._h, _ptr(u), _ptr(v), _ptr(t), _ptr(w), dt, _ptr(B4),
+                                       self._stream()))
+        return B4
+
+    def tem_stage2(self, ua, va, ta, wap, B4):
+        (u, v, t, w), dt = self._four(ua, va, ta, wap)
+        B3 = torch.empty((3, self.K, self.D), dtype=torch.float64, device=self.device)
+        check(self.lib.temx_tem_stage2(self._h, _ptr(u), _ptr(v), _ptr(t), _ptr(w), dt,
+                                       _ptr(B4.contiguous()), _ptr(B3), self._stream()))
+        return B3
+
+    def tem_stage3(self, B3, want_zonal=False):
+        res, zon = self._alloc_results(want_zonal)
+        check(self.lib.temx_tem_stage3(self._h, _ptr(B3.contiguous()), _ptr(res),
+                                       _ptr(zon) if zon is not None else None, self._stream()))
+        return res, zon
+
+    def tem_eddy(self, ua, va, ta, wap, names=_lib.EDDY_NAMES):
+        (u, v, t, w), dt = self._four(ua, va, ta, wap)
+        outs = {}
+        ptrs = (C.c_void_p * len(_lib.EDDY_NAMES))()
+        for i, n in enumerate(_lib.EDDY_NAMES):
+            if n in names:
+                outs[n] = torch.empty((self.N, self.nlev, self.nt), dtype=torch.float64, device=self.device)
+                ptrs[i] = outs[n].data_ptr()
+            else:
+                ptrs[i] = None
+        check(self.lib.temx_tem_eddy(self._h, _ptr(u), _ptr(v), _ptr(t), _ptr(w), dt, ptrs, self._stream()))
+        return outs
+
+    def status(self):
+        """Synchronise; True when a non-finite value reached the zonal sums (NaN input)."""
+        f = C.c_int(0)
+        check(self.lib.temx_status(self._h, C.byref(f), self._stream()))
+        return bool(f.value)
+
+    # ---- measurement helpers ----
+    def kernel_timing(self, enable=True):
+        check(self.lib.temx_kernel_timing(self._h, 1 if enable else 0))
+
+    def kernel_timing_read(self, which):
+        ms, n = C.c_double(0), C.c_int(0)
+        check(self.lib.temx_kernel_timing_read(self._h, which, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def synth_fields(device, lat_deg, lon_deg, plev_hpa, nt, t0=0, dtype=torch.float64, seed=0):
+    """SURVEY 8(d) synthetic fields generated in place on the device (bench / tests)."""
+    lib = _lib.load()
+    dev = torch.device("cuda", int(device))
+    lat = torch.as_tensor(np.asarray(lat_deg, dtype=np.float64), device=dev)
+    lon = torch.as_tensor(np.asarray(lon_deg, dtype=np.float64), device=dev)
+    pl = torch.as_tensor(np.asarray(plev_hpa, dtype=np.float64), device=dev)
+    N, nlev = lat.numel(), pl.numel()
+    outs = [torch.empty((N, nlev, nt), dtype=dtype, device=dev) for _ in range(4)]
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    check(lib.temx_synth_fields(int(device), N, nlev, nt, t0, _ptr(lat), _ptr(lon), _ptr(pl), _DT[dtype],
+                                seed, *[_ptr(o) for o in outs], st))
+    torch.cuda.current_stream(dev).synchronize()   # lat/lon/pl temporaries stay alive until done
+    return outs
+
+
+def mfma_f64_peak(device=0, iters=20000):
+    lib = _lib.load()
+    t = C.c_double(0)
+    check(lib.temx_mfma_f64_peak(int(device), iters, C.byref(t)))
+    return t.value

@@ -1,0 +1,150 @@
+"""GPU parity tests of the C-ABI engine (libtemx.so) against the CPU oracle and the goldens the
+reference itself produced.  Tolerances: fp64 <= 1e-10 field-normalised
+(max|d| / max|ref|); fp32 inputs <= 2e-5."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, fieldnorm_err
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+TOL64, TOL32 = 1e-10, 2e-5
+
+
+@pytest.fixture(scope="module")
+def eng():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test needs a GPU")
+    from pytemdiags_amd import engine
+    return engine
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x), device="cuda:0")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def test_mfma_layout_project_asymmetric(eng):
+    """Y0^T A against numpy on asymmetric random data, ragged N and D (fragment-layout check)."""
+    from oracle import tem_oracle as orc
+    rng = np.random.default_rng(0)
+    for N, D, L in [(1000, 37, 50), (866, 1, 50), (2500, 72, 20), (333, 130, 63), (64, 16, 3)]:
+        lat = rng.uniform(-90, 90, N)
+        lat_out = np.linspace(-88, 88, 45)
+        plan = eng.Plan(lat, lat_out, L)
+        Y0 = orc.ylm0_matrix_recurrence(lat, L)
+        Y0d = plan.matrix(0).cpu().numpy()
+        assert np.max(np.abs(Y0d - orc.ylm0_matrix(lat, L))) < 2e-12
+        assert np.max(np.abs(Y0d - Y0)) < 1e-13
+        Y0pd = plan.matrix(1).cpu().numpy()
+        assert np.max(np.abs(Y0pd - orc.ylm0_matrix(lat_out, L))) < 2e-12
+        A = rng.standard_normal((N, D))
+        B = plan.project(dev(A)).cpu().numpy()
+        ref = Y0d.T @ A
+        assert B.shape == ref.shape
+        assert np.max(np.abs(B - ref)) <= 1e-12 * np.max(np.abs(ref)) * np.sqrt(N), (N, D, L)
+        G = plan.matrix(2).cpu().numpy()
+        assert np.max(np.abs(G - Y0d.T @ Y0d)) <= 1e-12 * np.max(np.abs(G))
+        plan.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_zonal_mean_operator_vs_goldens(eng, dtype):
+    g = load("op_ne4_L30")
+    plan = eng.Plan(g["lat"], g["lat_out"], int(g["L"]))
+    for k in ("y20", "y21", "sinlon", "lat2p1", "rand3d"):
+        A = g["in_" + k].astype(dtype)
+        tol = TOL64 if dtype == np.float64 else TOL32
+        den = max(1.0, float(np.max(np.abs(A))))
+        zm = plan.zonal_mean(dev(A)).cpu().numpy()
+        zmn = plan.zonal_mean(dev(A), native=True).cpu().numpy()
+        assert zm.shape == g["zm_" + k].shape and zmn.shape == g["zmn_" + k].shape
+        assert np.max(np.abs(zm - g["zm_" + k])) <= tol * den, k
+        assert np.max(np.abs(zmn - g["zmn_" + k])) <= tol * den, k
+    assert not plan.status()
+    plan.close()
+
+
+@pytest.mark.parametrize("case", ["tem_ne4_30x1_f64", "tem_ne4_30x1_f32", "tem_ne4_12x3_L20_dlat3",
+                                  "tem_ne8_20x2_f64"])
+def test_tem_pipeline_vs_reference_goldens(eng, case):
+    from pytemdiags_amd import _lib
+    g = load(case)
+    f32 = g["ua"].dtype == np.float32
+    tol = TOL32 if f32 else TOL64
+    plan = eng.Plan(g["lat"], g["lat_zm"], int(g["L"]))
+    nlev, nt = g["ua"].shape[1:]
+    plan.set_tem(nlev, nt, g["plev"] * 100)
+    res, zon = plan.tem_run(dev(g["ua"]), dev(g["va"]), dev(g["ta"]), dev(g["wap"]), want_zonal=True)
+    assert not plan.status()
+    res, zon = res.cpu().numpy(), zon.cpu().numpy()
+    for i, n in enumerate(_lib.RESULT_NAMES):
+        e = fieldnorm_err(res[i], g["res_" + n])
+        assert e <= tol, (n, e)
+    for i, n in enumerate(_lib.ZONAL_NAMES):
+        e = fieldnorm_err(zon[i], g["zm_" + n])
+        assert e <= tol, (n, e)
+    if "nat_up" in g.files:
+        ed = plan.tem_eddy(dev(g["ua"]), dev(g["va"]), dev(g["ta"]), dev(g["wap"]))
+        for n in _lib.EDDY_NAMES:
+            e = fieldnorm_err(ed[n].cpu().numpy(), g["nat_" + n])
+            assert e <= tol, (n, e)
+    plan.close()
+
+
+def test_staged_equals_fused_and_nan_flag(eng):
+    g = load("tem_ne4_12x3_L20_dlat3")
+    plan = eng.Plan(g["lat"], g["lat_zm"], int(g["L"]))
+    nlev, nt = g["ua"].shape[1:]
+    plan.set_tem(nlev, nt, g["plev"] * 100)
+    f = [dev(g[k]) for k in ("ua", "va", "ta", "wap")]
+    res, _ = plan.tem_run(*f)
+    B4 = plan.tem_stage1(*f)
+    B3 = plan.tem_stage2(*f, B4)
+    res2, _ = plan.tem_stage3(B3)
+    assert torch.equal(res, res2)           # deterministic fixed-order reductions
+    res3, _ = plan.tem_run(*f)
+    assert torch.equal(res, res3)
+    assert not plan.status()
+    bad = g["ua"].copy()
+    bad[17, 3, 1] = np.nan                  # reference raises on NaN (sph_zonal_mean.py:219-221)
+    plan.tem_run(dev(bad), *f[1:])
+    assert plan.status()
+    assert not plan.status()                # flag is cleared by the read
+    plan.close()
+
+
+def test_weights_mode(eng):
+    """Y0inv = Y0^T diag(4 pi w)  (sph_zonal_mean.py:180-181, 383-386)."""
+    from oracle import tem_oracle as orc
+    g = load("op_ne4_L30")
+    N = g["lat"].size
+    w = np.full(N, 1.0 / N)
+    plan = eng.Plan(g["lat"], g["lat_out"], 10, defer_finalize=True)
+    plan.set_weights(w)
+    Z = orc.ZonalAverager(g["lat"], g["lat_out"], 10, weights=w)
+    A = g["in_rand3d"]
+    zm = plan.zonal_mean(dev(A)).cpu().numpy()
+    assert fieldnorm_err(zm, Z.zonal_mean(A)) < 1e-12
+    plan.close()
+
+
+def test_errors_are_loud(eng):
+    from pytemdiags_amd._lib import TemxError
+    with pytest.raises(TemxError):
+        eng.Plan(np.zeros(10), np.linspace(-80, 80, 9), 70)          # L > 63 unsupported
+    with pytest.raises(TemxError):
+        eng.Plan(np.full(200, 12.5), np.linspace(-80, 80, 9), 5)     # rank deficient (one latitude)
+    plan = eng.Plan(np.linspace(-89, 89, 300), np.linspace(-80, 80, 9), 5)
+    with pytest.raises(TemxError):
+        plan.tem_run(*[torch.zeros(300, 4, 1, device="cuda:0", dtype=torch.float64)] * 4)  # set_tem missing
+    with pytest.raises(TemxError):
+        plan.set_tem(1, 1, np.array([100.0]))
+    plan.close()
