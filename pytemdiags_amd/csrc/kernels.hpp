@@ -2,22 +2,26 @@
 //
 // Vocabulary (reference: PyTEMDiags/sph_zonal_mean.py, tem_diagnostics.py):
 //   N  = ncol native columns, K = L+1 harmonics, M zonal-grid latitudes, D = nlev*nt,
-//   field  = [N][D] row-major,  chunk = 16 consecutive native columns,
-//   d-tile = 16 consecutive (lev,time) columns, l-tile = 16 consecutive harmonics.
+//   field  = [N][D] row-major,  group = 4 consecutive native columns, chunk = 4 groups,
+//   d-tile = 16 consecutive (lev,time) columns, l-block = 4 consecutive harmonics (TB per row).
 //
-// MFMA used everywhere: v_mfma_f64_16x16x4_f64 (one wave, D[16x16] += A[16x4] B[4x16]):
-//   A operand: lane holds A[row = lane&15][k = lane>>4]
-//   B operand: lane holds B[k = lane>>4][col = lane&15]
-//   C/D      : lane holds 4 values, reg r <-> D[row = (lane>>4) + 4r][col = lane&15]
-// The C/D map means register r of a result tile IS the B operand of k-step r of a following
-// product that contracts over the tile's rows (k-order row = 4r + (lane>>4)); the eddy sweep
-// uses that to feed u'v' etc. straight back into the projection with no lane movement.
+// Matrix instruction: v_mfma_f64_4x4x4_4b_f64 (4 independent 4x4x4 blocks per wave).  Measured on
+// MI355X (tools/ubench_f64.hip): 18 cycles/instruction/SIMD = 67-68 TFLOP/s already at one wave
+// per SIMD, against 105 cycles (48 TFLOP/s) for v_mfma_f64_16x16x4_f64 and 57 TFLOP/s for
+// v_fma_f64 -- so this is the fp64 primitive the sweeps are tiled for.  Lane maps, probed with
+// one-hot operands (tools/probe_mfma4.hip):
+//   A: lane = 16 k + 4 b + i      B: lane = 16 k + 4 b + j      D: lane = 16 i + 4 b + j
+// Mapping block b to column group 4b..4b+3 makes one instruction a [4 x 4] . [4 x 16] product:
+//   B / D operands: lane holds element [row = lane>>4][col = lane&15] of a 4 x 16 tile -- the
+//     natural coalesced layout of 4 rows x 128 B of a field, and a D tile is directly the B
+//     operand of a following product that contracts over its rows;
+//   A operand: a 4 x 4 block, element [i = lane&3][k = lane>>4], replicated over the 4 blocks:
+//     16 doubles = one 128-byte line, read by every lane as a broadcast.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef double v4d __attribute__((ext_vector_type(4)));
-#define TEMX_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+#define TEMX_MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
 
 namespace temx {
 
@@ -32,33 +36,31 @@ struct EddyOut {
 
 // ------------------------------------------------------------------------------------------------
 // ylm0_basis: replaces the scipy.special.sph_harm loops (sph_zonal_mean.py:360-363, 367-370).
-// Y_l^0 = sqrt((2l+1)/4pi) P_l(x), x = cos(colat); (l+1) P_{l+1} = (2l+1) x P_l - l P_{l-1}.
-// One thread per native column; writes the canonical row-major matrix and the two
-// MFMA-fragment-major copies the sweeps stream:
-//   yproj[chunk][lt][s][lane] = Y0[16 chunk + 4 s + (lane>>4)][16 lt + (lane&15)]   (A operand, rows = l)
-//   yrec [chunk][s ][lane]    = Y0[16 chunk + (lane&15)][4 s + (lane>>4)]           (A operand, rows = i)
+// Y_l^0 = sqrt((2l+1)/4pi) P_l(x), x = cos(colat); l P_l = (2l-1) x P_{l-1} - (l-1) P_{l-2}.
+// One thread per native column; writes the canonical row-major matrix and the 4x4-blocked copy
+// the sweeps stream as MFMA A operands:
+//   yblk[group][t][k*4 + i] = Y0[4 group + k][4 t + i]        (t < TB, 128 B per block)
 // Rows >= N and harmonics >= K are zero, so tails need no masking in the sweeps.
+// rowscale (weights mode, sph_zonal_mean.py:385) scales the blocked copy only.
 // ------------------------------------------------------------------------------------------------
-__global__ void basis_kernel(const double* __restrict__ x, int64_t N, int64_t nchunk, int K, int LT,
-                             int S, const double* __restrict__ norm, const double* __restrict__ rowscale,
-                             double* __restrict__ Y0, double* __restrict__ yproj,
-                             double* __restrict__ yrec) {
+__global__ void basis_kernel(const double* __restrict__ x, int64_t N, int64_t nrow_pad, int K, int TB,
+                             const double* __restrict__ norm, const double* __restrict__ rowscale,
+                             double* __restrict__ Y0, double* __restrict__ yblk) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= nchunk * 16) return;
+  if (i >= nrow_pad) return;
   const bool valid = i < N;
   const double xv = valid ? x[i] : 0.0;
   const double rs = (valid && rowscale) ? rowscale[i] : 1.0;
-  const int64_t chunk = i >> 4;
-  const int r16 = (int)(i & 15);
+  const int64_t group = i >> 2;
+  const int k = (int)(i & 3);
   double pm1 = 1.0, pc = xv;
-  for (int l = 0; l < 16 * LT; ++l) {
+  for (int l = 0; l < 4 * TB; ++l) {
     double P;
     if (l == 0) {
       P = 1.0;
     } else if (l == 1) {
       P = xv;
     } else {
-      // l-1 -> l :  l P_l = (2l-1) x P_{l-1} - (l-1) P_{l-2}
       double pn = ((2 * l - 1) * xv * pc - (l - 1) * pm1) / l;
       pm1 = pc;
       pc = pn;
@@ -66,21 +68,22 @@ __global__ void basis_kernel(const double* __restrict__ x, int64_t N, int64_t nc
     }
     const double val = (valid && l < K) ? norm[l] * P : 0.0;
     if (Y0 && valid && l < K) Y0[i * K + l] = val;
-    if (yproj)
-      yproj[(((chunk * LT + (l >> 4)) * 4 + (r16 >> 2)) * 64) + (r16 & 3) * 16 + (l & 15)] = val * rs;
-    if (yrec && l < 4 * S) yrec[((chunk * S + (l >> 2)) * 64) + (l & 3) * 16 + r16] = val;
+    if (yblk) yblk[((group * TB + (l >> 2)) * 16) + k * 4 + (l & 3)] = val * rs;
   }
 }
 
 // wave-work decomposition shared by the sweeps: work id -> (split over chunks, d-tile).
 // Workgroups are dealt to XCDs round-robin (blockIdx % 8); remapping so that each XCD owns a
 // contiguous run of work ids keeps the d-tiles of one chunk range (which stream the same
-// Y0 fragments) behind one L2.
-__device__ __forceinline__ bool wave_work(int ndt, int nsplit, int& split, int& dt) {
-  const int wave = threadIdx.x >> 6;
+// Y0 blocks) behind one L2.
+__device__ __forceinline__ int uniform_wave() {
+  return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // SGPR: addresses stay scalar
+}
+
+__device__ __forceinline__ bool wave_work(int wave4, int ndt, int nsplit, int& split, int& dt) {
   const int cpx = gridDim.x >> 3;
   const int w = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
-  const int64_t id = (int64_t)w * 4 + wave;
+  const int64_t id = (int64_t)w * 4 + wave4;
   if (id >= (int64_t)ndt * nsplit) return false;
   split = (int)(id / ndt);
   dt = (int)(id % ndt);
@@ -92,70 +95,75 @@ __device__ __forceinline__ bool wave_work(int ndt, int nsplit, int& split, int& 
 // Replaces the inner np.matmul(Y0inv, AA) of sph_zonal_mean.py:251 (reduction over ncol); the
 // G^-1 factor is applied afterwards on the K x D sums (solve_kernel).  For the TEM pipeline NF=4
 // with theta = T (p0/p)^kappa fused into the load of field `sfield` (tem_diagnostics.py:498).
-// One wave owns one d-tile and all LT l-tiles of all NF fields: NF*LT accumulators, no LDS,
-// no barriers; X is read exactly once from HBM, register double-buffered one chunk ahead.
+// One wave owns one d-tile and all TB l-blocks of all NF fields (NF*TB accumulator registers);
+// no LDS, no barriers.  X is read exactly once from HBM, re-loaded one chunk ahead into the
+// registers it has just been consumed from; Y0 blocks (L2) run TB operands ahead in a ring.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NF, int LT>
+template <typename T, int NF, int TB>
 __global__ void __launch_bounds__(256, 2)
-project_kernel(FieldPtrs<NF> fp, int64_t N, int64_t D, int K, const double* __restrict__ yproj,
+project_kernel(FieldPtrs<NF> fp, int64_t N, int64_t D, int K, const double* __restrict__ yblk,
                int64_t nchunk, const double* __restrict__ colscale, int sfield,
                double* __restrict__ partial, int nsplit, int ndt) {
   int split, dt;
-  if (!wave_work(ndt, nsplit, split, dt)) return;
+  if (!wave_work(uniform_wave(), ndt, nsplit, split, dt)) return;
   const int lane = threadIdx.x & 63;
   const int c = lane & 15, g = lane >> 4;
   const int64_t d = (int64_t)dt * 16 + c;
   const bool dvalid = d < D;
   const int64_t dcl = dvalid ? d : D - 1;
-  const int64_t c0 = nchunk * split / nsplit, c1 = nchunk * (split + 1) / nsplit;
+  const int c0 = (int)(nchunk * split / nsplit), c1 = (int)(nchunk * (split + 1) / nsplit);   // uniform
 
+  // addressing: wave-uniform base (SGPR) + one 32-bit lane offset
+  const uint32_t loff = (uint32_t)(g * D + dcl);          // host guarantees 4*D < 2^31
+  const uint32_t yoff = (uint32_t)(g * 4 + (lane & 3));   // A[i = lane&3 -> l][k = lane>>4 -> row]
   double sc[NF];
-  const T* xp[NF];
 #pragma unroll
-  for (int f = 0; f < NF; ++f) {
-    sc[f] = (colscale != nullptr && f == sfield) ? colscale[dcl] : 1.0;
-    xp[f] = reinterpret_cast<const T*>(fp.p[f]) + dcl;
-  }
-  const double* yp = yproj + lane;
+  for (int f = 0; f < NF; ++f) sc[f] = (colscale != nullptr && f == sfield) ? colscale[dcl] : 1.0;
 
-  v4d acc[NF][LT];
+  double acc[NF][TB];
 #pragma unroll
   for (int f = 0; f < NF; ++f)
 #pragma unroll
-    for (int lt = 0; lt < LT; ++lt) acc[f][lt] = v4d{0.0, 0.0, 0.0, 0.0};
+    for (int t = 0; t < TB; ++t) acc[f][t] = 0.0;
 
-  // rolling prefetch at k-step granularity: the operands of k-step s are copied out, the same
-  // registers are immediately re-loaded with k-step s of the NEXT chunk (one chunk = 16*NF*LT
-  // MFMAs of cover), then the MFMAs of the step issue.
   T xn[NF][4];
-  double an[LT][4];
-  auto load_step = [&](int64_t chunk, int s) {
-    int64_t row = chunk * 16 + g + 4 * s;
-    row = row < N ? row : N - 1;
+  double yn[TB];
+  auto load_x = [&](int chunk, int ti) {
+    const int64_t gb = (int64_t)chunk * 16 + ti * 4;   // first row of the group (uniform)
+    if (gb + 4 <= N) {
 #pragma unroll
-    for (int f = 0; f < NF; ++f) xn[f][s] = xp[f][row * D];
+      for (int f = 0; f < NF; ++f) xn[f][ti] = (reinterpret_cast<const T*>(fp.p[f]) + gb * D)[loff];
+    } else {                                  // ragged tail of the grid: clamp per lane
+      int64_t row = gb + g;
+      row = row < N ? row : N - 1;
 #pragma unroll
-    for (int lt = 0; lt < LT; ++lt) an[lt][s] = yp[((chunk * LT + lt) * 4 + s) * 64];
+      for (int f = 0; f < NF; ++f) xn[f][ti] = reinterpret_cast<const T*>(fp.p[f])[row * D + dcl];
+    }
   };
+  // yblk is padded by one chunk of zero blocks, so running one group ahead never leaves it
+  auto load_y = [&](int64_t group, int t) { yn[t] = (yblk + (group * TB + t) * 16)[yoff]; };
 
   if (c0 < c1) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) load_step(c0, s);
+    for (int ti = 0; ti < 4; ++ti) load_x(c0, ti);
+#pragma unroll
+    for (int t = 0; t < TB; ++t) load_y((int64_t)c0 * 4, t);
   }
-  for (int64_t chunk = c0; chunk < c1; ++chunk) {
+  for (int chunk = c0; chunk < c1; ++chunk) {
     const bool more = chunk + 1 < c1;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      double xs[NF], as[LT];
+    for (int ti = 0; ti < 4; ++ti) {
+      double xs[NF];
 #pragma unroll
-      for (int f = 0; f < NF; ++f) xs[f] = (double)xn[f][s] * sc[f];
+      for (int f = 0; f < NF; ++f) xs[f] = (double)xn[f][ti] * sc[f];
+      if (more) load_x(chunk + 1, ti);
 #pragma unroll
-      for (int lt = 0; lt < LT; ++lt) as[lt] = an[lt][s];
-      if (more) load_step(chunk + 1, s);
+      for (int t = 0; t < TB; ++t) {
+        const double ya = yn[t];
+        load_y((int64_t)chunk * 4 + ti + 1, t);
 #pragma unroll
-      for (int lt = 0; lt < LT; ++lt)
-#pragma unroll
-        for (int f = 0; f < NF; ++f) acc[f][lt] = TEMX_MFMA(as[lt], xs[f], acc[f][lt]);
+        for (int f = 0; f < NF; ++f) acc[f][t] = TEMX_MFMA4(ya, xs[f], acc[f][t]);
+      }
     }
   }
 
@@ -163,12 +171,10 @@ project_kernel(FieldPtrs<NF> fp, int64_t N, int64_t D, int K, const double* __re
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
-      for (int lt = 0; lt < LT; ++lt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int l = lt * 16 + g + 4 * r;
-          if (l < K) partial[(((int64_t)split * NF + f) * K + l) * D + d] = acc[f][lt][r];
-        }
+      for (int t = 0; t < TB; ++t) {
+        const int l = t * 4 + g;
+        if (l < K) partial[(((int64_t)split * NF + f) * K + l) * D + d] = acc[f][t];
+      }
   }
 }
 
@@ -229,177 +235,231 @@ solve_kernel(const double* __restrict__ B, int K, int K4, int M, int64_t D,
 }
 
 // ------------------------------------------------------------------------------------------------
-// eddy / flux sweep (the dominant kernel).  Per 16x16 (chunk x d-tile) tile, one wave:
-//   xbar_f = Y0[chunk] . C_f                (4 reconstructions, MFMA, k = harmonics)
+// eddy / flux sweep (the dominant kernel).  Per chunk (16 columns) x d-tile (16), one wave:
+//   xbar_f = Y0[chunk] . C_f                (4 reconstructions; contraction over harmonics)
 //            = sph_zonal_mean_native of tem_diagnostics.py:517-529, never stored
 //   x'_f   = x_f - xbar_f                    (eddies; theta = T (p0/p)^kappa fused in the load)
 //   u'v', u'w', v'theta'                     (tem_diagnostics.py:547-555)
-//   partial[q][l][d] += Y0[chunk]^T . (product q)    (3 projections, MFMA, k = columns)
-// The coefficient B-operands (4 fields x S k-steps) are loop invariant per wave; they live in a
-// wave-private LDS slab written and read by the same lane (no barrier anywhere).
+//   partial[q][l][d] += Y0[chunk]^T . (product q)    (3 projections; contraction over columns)
+// = 8*TB A operands and 28*TB MFMAs per chunk.  The reconstruction result tile has the B-operand
+// layout, so the products feed the projection with no lane movement.
+// The coefficient B operands (4 fields x TB k-steps x 16 columns) are loop invariant per d-tile;
+// they live in an LDS slab shared by the two waves (wave, wave+4) that split the chunk range of
+// that d-tile.  Each wave writes the whole slab itself before reading it (identical values from
+// both writers), so no barrier is needed anywhere.  Y0 blocks arrive through a TB-deep ring.
 // MODE 1 additionally stores the eddies / products (lazy properties up, vp, ... of :420-433).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int LT, int SREC, int MODE>
-__global__ void __launch_bounds__(256, 1)
-eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, int S_rt, const double* __restrict__ yproj,
-            const double* __restrict__ yrec, int64_t nchunk, const double* __restrict__ colscale,
+constexpr int EDDY_GR = 2;   // groups (of 4 columns) per eddy step: 8 columns x 16 (lev,time)
+
+// offset (in doubles, relative to the step's first block) of A operand m of an eddy step:
+// m < GR*TB: reconstruction (s = m/GR, ti = m%GR); else projection (ti, tl); m >= 2*GR*TB rolls
+// into the next step (the blocked array is padded, so the last step may run ahead harmlessly).
+template <int TB>
+__device__ __forceinline__ constexpr int y_operand_off(int m) {
+  constexpr int GR = EDDY_GR;
+  int roll = 0;
+  if (m >= 2 * GR * TB) {
+    m -= 2 * GR * TB;
+    roll = GR * TB * 16;
+  }
+  if (m < GR * TB) return roll + ((m % GR) * TB + (m / GR)) * 16;
+  const int mm = m - GR * TB;
+  return roll + ((mm / TB) * TB + (mm % TB)) * 16;
+}
+template <int TB>
+__device__ __forceinline__ constexpr bool y_operand_is_recon(int m) {
+  constexpr int GR = EDDY_GR;
+  if (m >= 2 * GR * TB) m -= 2 * GR * TB;
+  return m < GR * TB;
+}
+
+template <typename T, int TB, int MODE>
+__global__ void __launch_bounds__(512, 2)
+eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restrict__ yblk_r,
+            const double* __restrict__ yblk_p, int64_t nchunk, const double* __restrict__ colscale,
             const double* __restrict__ C, double* __restrict__ partial, int nsplit, int ndt,
             EddyOut eo) {
   extern __shared__ double lds[];
-  constexpr int SMAX = SREC > 0 ? SREC : 4 * LT;
-  const int S = SREC > 0 ? SREC : S_rt;
+  constexpr int GR = EDDY_GR;
+  const int wave = uniform_wave(), lane = threadIdx.x & 63;
+  const int w4 = wave & 3, half = wave >> 2;
   int split, dt;
-  if (!wave_work(ndt, nsplit, split, dt)) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (!wave_work(w4, ndt, nsplit, split, dt)) return;
   const int c = lane & 15, g = lane >> 4;
   const int64_t d = (int64_t)dt * 16 + c;
   const bool dvalid = d < D;
   const int64_t dcl = dvalid ? d : D - 1;
-  const int64_t c0 = nchunk * split / nsplit, c1 = nchunk * (split + 1) / nsplit;
-  const int K4 = 4 * S;
+  const int64_t nstep = nchunk * (4 / GR);
+  const int s0 = (int)(nstep * split / nsplit), s1 = (int)(nstep * (split + 1) / nsplit);
+  const int sm = s0 + (s1 - s0 + 1) / 2;
+  const int c0 = half ? sm : s0, c1 = half ? s1 : sm;   // uniform (SGPR)
 
-  // coefficient B operands -> wave-private LDS: cb[f][s][lane] = C_f[4 s + g][d]
-  double* cb = lds + (size_t)wave * (4 * SMAX * 64) + lane;
+  // coefficient B operands: cb[f][s][lane] = C_f[4 s + g][d]
+  double* cb = lds + (size_t)w4 * (4 * TB * 64) + lane;
 #pragma unroll
   for (int f = 0; f < 4; ++f)
 #pragma unroll
-    for (int s = 0; s < SMAX; ++s)
-      if (s < S) cb[(f * SMAX + s) * 64] = C[((int64_t)f * K4 + 4 * s + g) * D + dcl];
+    for (int s = 0; s < TB; ++s) cb[(f * TB + s) * 64] = C[((int64_t)f * 4 * TB + 4 * s + g) * D + dcl];
 
+  int cbi = w4 * (4 * TB * 64) + lane;   // index of this lane's first slab element in lds[]
   const double sth = colscale != nullptr ? colscale[dcl] : 1.0;
-  const T* xp[4];
-#pragma unroll
-  for (int f = 0; f < 4; ++f) xp[f] = reinterpret_cast<const T*>(fp.p[f]) + dcl;
-  const double* ypp = yproj + lane;
-  const double* yrp = yrec + lane;
+  const uint32_t loff = (uint32_t)(g * D + dcl);
+  const uint32_t aoff_r = (uint32_t)((lane & 3) * 4 + g);   // reconstruction A[i -> column][k -> harmonic]
+  const uint32_t aoff_p = (uint32_t)(g * 4 + (lane & 3));   // projection     A[i -> harmonic][k -> column]
+  // (the reconstruction always uses the unscaled Y0; yblk_p differs only in weights mode)
 
-  v4d acc[3][LT];
+  double acc[3][TB];
 #pragma unroll
   for (int q = 0; q < 3; ++q)
 #pragma unroll
-    for (int lt = 0; lt < LT; ++lt) acc[q][lt] = v4d{0.0, 0.0, 0.0, 0.0};
+    for (int t = 0; t < TB; ++t) acc[q][t] = 0.0;
 
-  T xn[4][4];
-  double yan[SMAX];
-  auto load = [&](int64_t chunk) {
-    const int64_t row0 = chunk * 16 + g;
+  T xn[4][GR];
+  double ring[TB];
+  auto load_x = [&](int step) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int64_t row = row0 + 4 * r;
-      row = row < N ? row : N - 1;
+    for (int ti = 0; ti < GR; ++ti) {
+      const int64_t gb = ((int64_t)step * GR + ti) * 4;
+      if (gb + 4 <= N) {
 #pragma unroll
-      for (int f = 0; f < 4; ++f) xn[f][r] = xp[f][row * D];
-    }
+        for (int f = 0; f < 4; ++f) xn[f][ti] = (reinterpret_cast<const T*>(fp.p[f]) + gb * D)[loff];
+      } else {
+        int64_t row = gb + g;
+        row = row < N ? row : N - 1;
 #pragma unroll
-    for (int s = 0; s < SMAX; ++s)
-      if (s < S) yan[s] = yrp[(chunk * S + s) * 64];
-  };
-
-  if (c0 < c1) load(c0);
-  for (int64_t chunk = c0; chunk < c1; ++chunk) {
-    double xc[4][4], ya[SMAX], ap[LT][4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) xc[f][r] = (double)xn[f][r];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) xc[2][r] *= sth;
-#pragma unroll
-    for (int s = 0; s < SMAX; ++s) ya[s] = yan[s];
-    // projection A operands of this chunk (L2); consumed after the reconstruction MFMAs
-#pragma unroll
-    for (int lt = 0; lt < LT; ++lt)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) ap[lt][s] = ypp[((chunk * LT + lt) * 4 + s) * 64];
-    if (chunk + 1 < c1) load(chunk + 1);
-
-    v4d rec[4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) rec[f] = v4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int s = 0; s < SMAX; ++s)
-      if (s < S) {
-#pragma unroll
-        for (int f = 0; f < 4; ++f) rec[f] = TEMX_MFMA(ya[s], cb[(f * SMAX + s) * 64], rec[f]);
+        for (int f = 0; f < 4; ++f) xn[f][ti] = reinterpret_cast<const T*>(fp.p[f])[row * D + dcl];
       }
+    }
+  };
+#define TEMX_YOP(step_, m_)                                                                        \
+  (y_operand_is_recon<TB>(m_)                                                                      \
+       ? (yblk_r + (int64_t)(step_) * (GR * TB * 16) + y_operand_off<TB>(m_))[aoff_r]              \
+       : (yblk_p + (int64_t)(step_) * (GR * TB * 16) + y_operand_off<TB>(m_))[aoff_p])
 
-    double e[4][4], p[3][4];
+  if (c0 < c1) {
+    load_x(c0);
+#pragma unroll
+    for (int m = 0; m < TB; ++m) ring[m] = TEMX_YOP(c0, m);
+  }
+  for (int step = c0; step < c1; ++step) {
+    double xs[4][GR];
 #pragma unroll
     for (int f = 0; f < 4; ++f)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) e[f][r] = xc[f][r] - rec[f][r];
+      for (int ti = 0; ti < GR; ++ti) xs[f][ti] = (double)xn[f][ti];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      p[0][r] = e[0][r] * e[1][r];   // u'v'
-      p[1][r] = e[0][r] * e[3][r];   // u'w'
-      p[2][r] = e[1][r] * e[2][r];   // v'theta'
+    for (int ti = 0; ti < GR; ++ti) xs[2][ti] *= sth;
+    if (step + 1 < c1) load_x(step + 1);
+
+    // The slab is loop invariant: without this, hipcc hoists all 4*TB LDS reads out of the loop
+    // into 8*TB registers and spills.  Laundering the index keeps them as in-loop ds_reads.
+    asm volatile("" : "+v"(cbi));
+    const double* cbr = lds + cbi;
+
+    // ---- reconstruction: rec[f][ti] = sum_s Y0blk[ti][s] . C_f[s] ----
+    double rec[4][GR];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int ti = 0; ti < GR; ++ti) rec[f][ti] = 0.0;
+    double cbv[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) cbv[f] = cbr[(f * TB) * 64];
+#pragma unroll
+    for (int s = 0; s < TB; ++s) {
+      double cbc[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) cbc[f] = cbv[f];
+      if (s + 1 < TB) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) cbv[f] = cbr[(f * TB + s + 1) * 64];
+      }
+#pragma unroll
+      for (int ti = 0; ti < GR; ++ti) {
+        const int m = s * GR + ti;
+        const double ya = ring[m % TB];
+        ring[m % TB] = TEMX_YOP(step, m + TB);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) rec[f][ti] = TEMX_MFMA4(ya, cbc[f], rec[f][ti]);
+      }
     }
-    if (MODE == 1) {
-      if (dvalid) {
+
+    // ---- eddies and products (tem_diagnostics.py:517-529, 547-555) ----
+    double p[3][GR];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t row = chunk * 16 + g + 4 * r;
-          if (row < N) {
-#pragma unroll
-            for (int f = 0; f < 4; ++f)
-              if (eo.p[f]) eo.p[f][row * D + d] = e[f][r];
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-              if (eo.p[4 + q]) eo.p[4 + q][row * D + d] = p[q][r];
-          }
+    for (int ti = 0; ti < GR; ++ti) {
+      const double eu = xs[0][ti] - rec[0][ti], ev = xs[1][ti] - rec[1][ti];
+      const double eth = xs[2][ti] - rec[2][ti], ew = xs[3][ti] - rec[3][ti];
+      p[0][ti] = eu * ev;    // u'v'
+      p[1][ti] = eu * ew;    // u'w'
+      p[2][ti] = ev * eth;   // v'theta'
+      if (MODE == 1) {
+        const int64_t row = ((int64_t)step * GR + ti) * 4 + g;
+        if (dvalid && row < N) {
+          const int64_t o = row * D + d;
+          if (eo.p[0]) eo.p[0][o] = eu;
+          if (eo.p[1]) eo.p[1][o] = ev;
+          if (eo.p[2]) eo.p[2][o] = eth;
+          if (eo.p[3]) eo.p[3][o] = ew;
+          if (eo.p[4]) eo.p[4][o] = p[0][ti];
+          if (eo.p[5]) eo.p[5][o] = p[1][ti];
+          if (eo.p[6]) eo.p[6][o] = p[2][ti];
         }
       }
     }
+
+    // ---- projection of the three products ----
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int ti = 0; ti < GR; ++ti)
 #pragma unroll
-      for (int lt = 0; lt < LT; ++lt)
+      for (int t = 0; t < TB; ++t) {
+        const int m = GR * TB + ti * TB + t;
+        const double ya = ring[m % TB];
+        ring[m % TB] = TEMX_YOP(step, m + TB);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) acc[q][lt] = TEMX_MFMA(ap[lt][s], p[q][s], acc[q][lt]);
+        for (int q = 0; q < 3; ++q) acc[q][t] = TEMX_MFMA4(ya, p[q][ti], acc[q][t]);
+      }
   }
+#undef TEMX_YOP
 
   if (dvalid && partial != nullptr) {
+    const int64_t slab = (int64_t)split * 2 + half;
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
-      for (int lt = 0; lt < LT; ++lt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int l = lt * 16 + g + 4 * r;
-          if (l < K) partial[(((int64_t)split * 3 + q) * K + l) * D + d] = acc[q][lt][r];
-        }
+      for (int t = 0; t < TB; ++t) {
+        const int l = t * 4 + g;
+        if (l < K) partial[((slab * 3 + q) * K + l) * D + d] = acc[q][t];
+      }
   }
 }
 
 // native-grid zonal mean out[i][d] = sum_l Y0[i][l] C[l][d]  (sph_zonal_mean_native,
 // sph_zonal_mean.py:285-290, outer matmul with Y = Y0).  Same tile scheme as the eddy sweep.
-template <int LT>
-__global__ void __launch_bounds__(256, 1)
-recon_kernel(int64_t N, int64_t D, int S, const double* __restrict__ yrec, int64_t nchunk,
+template <int TB>
+__global__ void __launch_bounds__(256, 2)
+recon_kernel(int64_t N, int64_t D, const double* __restrict__ yblk, int64_t nchunk,
              const double* __restrict__ C, double* __restrict__ out, int nsplit, int ndt) {
   extern __shared__ double lds[];
-  constexpr int SMAX = 4 * LT;
   int split, dt;
-  if (!wave_work(ndt, nsplit, split, dt)) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave = uniform_wave();
+  if (!wave_work(wave, ndt, nsplit, split, dt)) return;
+  const int lane = threadIdx.x & 63;
   const int c = lane & 15, g = lane >> 4;
   const int64_t d = (int64_t)dt * 16 + c;
   const bool dvalid = d < D;
   const int64_t dcl = dvalid ? d : D - 1;
-  const int64_t c0 = nchunk * split / nsplit, c1 = nchunk * (split + 1) / nsplit;
-  double* cb = lds + (size_t)wave * (SMAX * 64) + lane;
-  for (int s = 0; s < S; ++s) cb[s * 64] = C[((int64_t)4 * s + g) * D + dcl];
-  const double* yrp = yrec + lane;
-  for (int64_t chunk = c0; chunk < c1; ++chunk) {
-    v4d rec = v4d{0.0, 0.0, 0.0, 0.0};
-    for (int s = 0; s < S; ++s) rec = TEMX_MFMA(yrp[(chunk * S + s) * 64], cb[s * 64], rec);
-    if (dvalid) {
+  const int64_t c0 = nchunk * 4 * split / nsplit, c1 = nchunk * 4 * (split + 1) / nsplit;  // groups
+  double* cb = lds + (size_t)wave * (TB * 64) + lane;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t row = chunk * 16 + g + 4 * r;
-        if (row < N) out[row * D + d] = rec[r];
-      }
-    }
+  for (int s = 0; s < TB; ++s) cb[s * 64] = C[((int64_t)4 * s + g) * D + dcl];
+  const double* yb = yblk + (lane & 3) * 4 + g;
+  for (int64_t group = c0; group < c1; ++group) {
+    double rec = 0.0;
+#pragma unroll
+    for (int s = 0; s < TB; ++s) rec = TEMX_MFMA4(yb[(group * TB + s) * 16], cb[s * 64], rec);
+    const int64_t row = group * 4 + g;
+    if (dvalid && row < N) out[row * D + d] = rec;
   }
 }
 
@@ -620,18 +680,20 @@ __global__ void synth_kernel(int64_t N, int nlev, int64_t nt, int64_t t0, const 
   }
 }
 
-// bare fp64 MFMA issue loop: 4 independent accumulators per wave, operands in registers.
+// bare fp64 MFMA issue loop (v_mfma_f64_4x4x4_4b_f64): 8 independent accumulators per wave.
 __global__ void __launch_bounds__(256) mfma_f64_peak_kernel(int iters, double* sink) {
-  v4d a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+  double a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = 0.0;
   double x = 1.0 + threadIdx.x * 1e-3, y = 0.5 - threadIdx.x * 1e-4;
   for (int i = 0; i < iters; ++i) {
-    a0 = TEMX_MFMA(x, y, a0);
-    a1 = TEMX_MFMA(y, x, a1);
-    a2 = TEMX_MFMA(x, x, a2);
-    a3 = TEMX_MFMA(y, y, a3);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = TEMX_MFMA4(x, y, a[j]);
   }
-  v4d r = a0 + a1 + a2 + a3;
-  if (r[0] + r[1] + r[2] + r[3] == 12345.678) sink[0] = r[0];
+  double r = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r += a[i];
+  if (r == 12345.678) sink[0] = r;
 }
 
 }  // namespace temx

@@ -77,9 +77,10 @@ struct TimedLaunch {
 struct temx_plan {
   int device = 0, num_cu = 256;
   int64_t N = 0, nchunk = 0;
-  int L = 0, K = 0, LT = 0, S = 0, K4 = 0, M = 0;
+  int L = 0, K = 0, TB = 0, K4 = 0, M = 0;
   bool finalized = false;
-  DevBuf x, Y0, yproj, yrec, Y0p, G, Ginv, norm, flag;
+  DevBuf x, Y0, yblk, yblk_w, Y0p, G, Ginv, norm, flag;
+  const double* yproj_ptr() const { return yblk_w.p ? yblk_w.d() : yblk.d(); }
   std::vector<double> lat_out_deg;
   // TEM configuration
   bool tem = false;
@@ -152,14 +153,14 @@ template <typename T, int NF>
 static int launch_project_t(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t D, const double* colscale,
                             int sfield, double* partial, const Split& sp, hipStream_t st) {
   dim3 grid(sp.grid), block(256);
-#define TEMX_LP(LTv)                                                                              \
-  hipLaunchKernelGGL((project_kernel<T, NF, LTv>), grid, block, 0, st, fp, pl->N, D, pl->K,       \
-                     pl->yproj.d(), pl->nchunk, colscale, sfield, partial, sp.nsplit, sp.ndt)
-  switch (pl->LT) {
-    case 1: TEMX_LP(1); break;
-    case 2: TEMX_LP(2); break;
-    case 3: TEMX_LP(3); break;
-    default: TEMX_LP(4); break;
+#define TEMX_LP(TBv)                                                                              \
+  hipLaunchKernelGGL((project_kernel<T, NF, TBv>), grid, block, 0, st, fp, pl->N, D, pl->K,       \
+                     pl->yproj_ptr(), pl->nchunk, colscale, sfield, partial, sp.nsplit, sp.ndt)
+  switch (pl->TB) {
+    case 4: TEMX_LP(4); break;
+    case 8: TEMX_LP(8); break;
+    case 13: TEMX_LP(13); break;
+    default: TEMX_LP(16); break;
   }
 #undef TEMX_LP
   HIPCHK(hipGetLastError());
@@ -196,27 +197,22 @@ static int launch_solve(temx_plan* pl, const double* B, int NF, int64_t D, doubl
 template <typename T, int MODE>
 static int launch_eddy_t(temx_plan* pl, const FieldPtrs<4>& fp, double* partial, const Split& sp,
                          const EddyOut& eo, hipStream_t st) {
-  dim3 grid(sp.grid), block(256);
-  const int SMAX_gen = 4 * pl->LT;
-#define TEMX_LE(LTv, SRECv, smax)                                                                     \
+  dim3 grid(sp.grid), block(512);
+#define TEMX_LE(TBv)                                                                                  \
   do {                                                                                                \
-    auto kern = eddy_kernel<T, LTv, SRECv, MODE>;                                                     \
-    const size_t lds = (size_t)4 * 4 * (smax)*64 * sizeof(double);                                    \
+    auto kern = eddy_kernel<T, TBv, MODE>;                                                            \
+    const size_t lds = (size_t)4 * 4 * TBv * 64 * sizeof(double);                                     \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
-    hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->N, pl->D, pl->K, pl->S, pl->yproj.d(),     \
-                       pl->yrec.d(), pl->nchunk, pl->colscale.d(), pl->C4.d(), partial, sp.nsplit,    \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->N, pl->D, pl->K, pl->yblk.d(),             \
+                       pl->yproj_ptr(), pl->nchunk, pl->colscale.d(), pl->C4.d(), partial, sp.nsplit, \
                        sp.ndt, eo);                                                                   \
   } while (0)
-  if (pl->LT == 4 && pl->S == 13) {
-    TEMX_LE(4, 13, 13);
-  } else {
-    switch (pl->LT) {
-      case 1: TEMX_LE(1, 0, SMAX_gen); break;
-      case 2: TEMX_LE(2, 0, SMAX_gen); break;
-      case 3: TEMX_LE(3, 0, SMAX_gen); break;
-      default: TEMX_LE(4, 0, SMAX_gen); break;
-    }
+  switch (pl->TB) {
+    case 4: TEMX_LE(4); break;
+    case 8: TEMX_LE(8); break;
+    case 13: TEMX_LE(13); break;
+    default: TEMX_LE(16); break;
   }
 #undef TEMX_LE
   HIPCHK(hipGetLastError());
@@ -224,20 +220,20 @@ static int launch_eddy_t(temx_plan* pl, const FieldPtrs<4>& fp, double* partial,
 }
 
 static int launch_recon(temx_plan* pl, int64_t D, const double* C, double* out, hipStream_t st) {
-  Split sp = choose_split(D, pl->nchunk, pl->num_cu);
+  Split sp = choose_split(D, pl->nchunk, 2 * pl->num_cu);
   dim3 grid(sp.grid), block(256);
-#define TEMX_LR(LTv)                                                                                  \
+#define TEMX_LR(TBv)                                                                                  \
   do {                                                                                                \
-    auto kern = recon_kernel<LTv>;                                                                    \
-    const size_t lds = (size_t)4 * (4 * LTv) * 64 * sizeof(double);                                   \
-    hipLaunchKernelGGL(kern, grid, block, lds, st, pl->N, D, pl->S, pl->yrec.d(), pl->nchunk, C, out, \
+    auto kern = recon_kernel<TBv>;                                                                    \
+    const size_t lds = (size_t)4 * TBv * 64 * sizeof(double);                                         \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, pl->N, D, pl->yblk.d(), pl->nchunk, C, out,        \
                        sp.nsplit, sp.ndt);                                                            \
   } while (0)
-  switch (pl->LT) {
-    case 1: TEMX_LR(1); break;
-    case 2: TEMX_LR(2); break;
-    case 3: TEMX_LR(3); break;
-    default: TEMX_LR(4); break;
+  switch (pl->TB) {
+    case 4: TEMX_LR(4); break;
+    case 8: TEMX_LR(8); break;
+    case 13: TEMX_LR(13); break;
+    default: TEMX_LR(16); break;
   }
 #undef TEMX_LR
   HIPCHK(hipGetLastError());
@@ -326,7 +322,7 @@ int temx_device_count(void) {
 void temx_plan_destroy(temx_plan* pl) {
   if (!pl) return;
   (void)hipSetDevice(pl->device);
-  DevBuf* bufs[] = {&pl->x, &pl->Y0, &pl->yproj, &pl->yrec, &pl->Y0p, &pl->G, &pl->Ginv, &pl->norm,
+  DevBuf* bufs[] = {&pl->x, &pl->Y0, &pl->yblk, &pl->yblk_w, &pl->Y0p, &pl->G, &pl->Ginv, &pl->norm,
                     &pl->flag, &pl->p, &pl->pg, &pl->lg, &pl->coslat, &pl->fcor, &pl->colscale,
                     &pl->B4, &pl->B3, &pl->C4, &pl->zb, &pl->partial, &pl->opB, &pl->opC};
   for (DevBuf* b : bufs) b->release();
@@ -338,11 +334,10 @@ void temx_plan_destroy(temx_plan* pl) {
   delete pl;
 }
 
-static int build_basis(temx_plan* pl, const double* rowscale_dev) {
+static int build_basis(temx_plan* pl, const double* rowscale_dev, double* Y0, double* yblk) {
   const int64_t npad = pl->nchunk * 16;
   hipLaunchKernelGGL(basis_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, 0, pl->x.d(), pl->N,
-                     pl->nchunk, pl->K, pl->LT, pl->S, pl->norm.d(), rowscale_dev, pl->Y0.d(),
-                     pl->yproj.d(), pl->yrec.d());
+                     npad, pl->K, pl->TB, pl->norm.d(), rowscale_dev, Y0, yblk);
   HIPCHK(hipGetLastError());
   return TEMX_OK;
 }
@@ -369,9 +364,9 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
   pl->nchunk = (ncol + 15) / 16;
   pl->L = L;
   pl->K = L + 1;
-  pl->LT = (pl->K + 15) / 16;
-  pl->S = (pl->K + 3) / 4;
-  pl->K4 = 4 * pl->S;
+  // l-blocks of 4 harmonics per row; the sweeps are instantiated for TB in {4, 8, 13, 16}
+  pl->TB = pl->K <= 16 ? 4 : (pl->K <= 32 ? 8 : (pl->K <= 52 ? 13 : 16));
+  pl->K4 = 4 * pl->TB;
   pl->M = M;
   pl->lat_out_deg.assign(lat_out_deg_host, lat_out_deg_host + M);
   int rc = TEMX_OK;
@@ -392,9 +387,10 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
   if ((rc = upload(pl->flag, &zero, sizeof(int)))) return bail(rc);
 
   if ((rc = pl->Y0.ensure((size_t)ncol * pl->K * 8))) return bail(rc);
-  if ((rc = pl->yproj.ensure((size_t)pl->nchunk * pl->LT * 4 * 64 * 8))) return bail(rc);
-  if ((rc = pl->yrec.ensure((size_t)pl->nchunk * pl->S * 64 * 8))) return bail(rc);
-  if ((rc = build_basis(pl, nullptr))) return bail(rc);
+  // one extra chunk of blocks: the sweeps prefetch A operands one group / step ahead
+  if ((rc = pl->yblk.ensure((size_t)(pl->nchunk + 1) * 4 * pl->TB * 16 * 8))) return bail(rc);
+  HIPCHK(hipMemset(pl->yblk.p, 0, pl->yblk.bytes));
+  if ((rc = build_basis(pl, nullptr, pl->Y0.d(), pl->yblk.d()))) return bail(rc);
 
   // Y0p on the output latitudes (sph_zonal_mean.py:367-370): same kernel, canonical copy only
   {
@@ -407,8 +403,8 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
     }
     const int64_t mch = (M + 15) / 16;
     hipLaunchKernelGGL(basis_kernel, dim3((unsigned)((mch * 16 + 255) / 256)), dim3(256), 0, 0, xo.d(),
-                       (int64_t)M, mch, pl->K, pl->LT, pl->S, pl->norm.d(), (const double*)nullptr,
-                       pl->Y0p.d(), (double*)nullptr, (double*)nullptr);
+                       (int64_t)M, mch * 16, pl->K, pl->TB, pl->norm.d(), (const double*)nullptr,
+                       pl->Y0p.d(), (double*)nullptr);
     hipError_t e = hipDeviceSynchronize();
     xo.release();
     if (e != hipSuccess) return bail(fail(TEMX_EHIP, "basis kernel failed: %s", hipGetErrorString(e)));
@@ -467,7 +463,13 @@ int temx_plan_set_weights(temx_plan* pl, const double* w_host) {
   DevBuf wd;
   int rc = upload(wd, w.data(), w.size() * 8);
   if (rc) return rc;
-  rc = build_basis(pl, wd.d());
+  rc = pl->yblk_w.ensure(pl->yblk.bytes);
+  if (rc) {
+    wd.release();
+    return rc;
+  }
+  (void)hipMemset(pl->yblk_w.p, 0, pl->yblk_w.bytes);
+  rc = build_basis(pl, wd.d(), nullptr, pl->yblk_w.d());
   hipError_t e = hipDeviceSynchronize();
   wd.release();
   if (rc) return rc;
@@ -512,7 +514,7 @@ int temx_get_matrix(temx_plan* pl, int which, double* dst, void* stream) {
 // ---- operator API --------------------------------------------------------------------------------
 int temx_project(temx_plan* pl, const void* A, int dtype, int64_t D, double* B, void* stream) {
   if (!pl || !A || !B) return fail(TEMX_EINVAL, "null argument");
-  if (D < 1) return fail(TEMX_EINVAL, "D must be >= 1");
+  if (D < 1 || D >= ((int64_t)1 << 28)) return fail(TEMX_EINVAL, "D must be in [1, 2^28)");
   HIPCHK(hipSetDevice(pl->device));
   Split sp = choose_split(D, pl->nchunk, 2 * pl->num_cu);
   int rc = pl->partial.ensure((size_t)sp.nsplit * pl->K * D * 8);
@@ -549,6 +551,7 @@ int temx_zonal_mean(temx_plan* pl, const void* A, int dtype, int64_t D, double* 
 int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_host, double p0) {
   if (!pl || !p_pa_host) return fail(TEMX_EINVAL, "null argument");
   if (nlev < 2 || nt < 1) return fail(TEMX_EINVAL, "need nlev >= 2 and nt >= 1");
+  if ((int64_t)nlev * nt >= ((int64_t)1 << 28)) return fail(TEMX_EINVAL, "nlev*nt must be < 2^28");
   if (pl->M < 2) return fail(TEMX_EINVAL, "need at least 2 zonal-mean latitudes");
   HIPCHK(hipSetDevice(pl->device));
   pl->nlev = nlev;
@@ -587,8 +590,10 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
   if ((rc = upload(pl->colscale, cs.data(), cs.size() * 8))) return rc;
 
   pl->sp_proj4 = choose_split(D, pl->nchunk, 2 * pl->num_cu);
-  pl->sp_eddy = choose_split(D, pl->nchunk, pl->num_cu);
-  const size_t need = (size_t)std::max(pl->sp_proj4.nsplit * 4, pl->sp_eddy.nsplit * 3) * pl->K * D * 8;
+  // eddy sweep: one 8-wave workgroup per CU (LDS slab), each work id is shared by two waves that
+  // halve its chunk range -> 2 partial slabs per split
+  pl->sp_eddy = choose_split(D, pl->nchunk / 2, pl->num_cu);
+  const size_t need = (size_t)std::max(pl->sp_proj4.nsplit * 4, pl->sp_eddy.nsplit * 2 * 3) * pl->K * D * 8;
   if ((rc = pl->partial.ensure(need))) return rc;
   if ((rc = pl->B4.ensure((size_t)4 * pl->K * D * 8))) return rc;
   if ((rc = pl->B3.ensure((size_t)3 * pl->K * D * 8))) return rc;
@@ -652,7 +657,7 @@ int temx_tem_stage2(temx_plan* pl, const void* ua, const void* va, const void* t
   rc = run_eddy(pl, ua, va, ta, wap, dtype, pl->partial.d(), nullptr, st);
   time_end(pl, 1, st, tl);
   if (rc) return rc;
-  return launch_reduce(pl, pl->partial.d(), pl->sp_eddy.nsplit, (int64_t)3 * pl->K * pl->D, B3, st);
+  return launch_reduce(pl, pl->partial.d(), pl->sp_eddy.nsplit * 2, (int64_t)3 * pl->K * pl->D, B3, st);
 }
 
 int temx_tem_stage3(temx_plan* pl, const double* B3, double* results, double* zonal, void* stream) {
@@ -748,7 +753,7 @@ int temx_mfma_f64_peak(int device, int iters, double* tflops_out) {
   HIPCHK(hipEventSynchronize(b));
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, a, b));
-  const double flops = (double)blocks * 4.0 * iters * 4.0 * 2048.0;
+  const double flops = (double)blocks * 4.0 * iters * 8.0 * 512.0;
   *tflops_out = flops / (ms * 1e-3) / 1e12;
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Quick timing of the TEM pipeline and its two sweeps (development aid)."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from pytemdiags_amd import engine, synth
+
+def run(ne, nlev, nt, reps=5, dtype=torch.float64):
+    lat, lon = synth.cubed_sphere_gll(ne)
+    plev = synth.pressure_levels(nlev)
+    lat_zm = (np.arange(-90, 91, 1.0)[1:] + np.arange(-90, 91, 1.0)[:-1]) / 2
+    t0 = time.time()
+    plan = engine.Plan(lat, lat_zm, 50)
+    plan.set_tem(nlev, nt, plev * 100)
+    torch.cuda.synchronize(); tplan = time.time() - t0
+    f = engine.synth_fields(0, lat, lon, plev, nt, dtype=dtype)
+    out = plan._alloc_results(False)
+    plan.tem_run(*f, out=out); torch.cuda.synchronize()
+    plan.kernel_timing(True)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        plan.tem_run(*f, out=out)
+    b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / reps
+    p_ms, _ = plan.kernel_timing_read(0); e_ms, _ = plan.kernel_timing_read(1)
+    pts = lat.size * nlev * nt
+    fl_p, fl_e = pts * 4 * 2 * 51, pts * 7 * 2 * 51
+    print("ne%d x %d x %d %s: N=%d pts=%.3g | plan %.2fs | total %.3f ms -> %.3g pts/s (%.1f%% of 7.0e10) | project %.3f ms "
+          "(%.1f TF alg, %.2f TB/s) | eddy %.3f ms (%.1f TF alg, %.2f TB/s) | rest %.3f ms | nonfinite=%s" % (
+          ne, nlev, nt, str(dtype)[6:], lat.size, pts, tplan, ms, pts / ms * 1e3, pts / ms * 1e3 / 7.0e10 * 100,
+          p_ms, fl_p / p_ms / 1e9, pts * 4 * f[0].element_size() / p_ms / 1e9,
+          e_ms, fl_e / e_ms / 1e9, pts * 4 * f[0].element_size() / e_ms / 1e9, ms - p_ms - e_ms, plan.status()), flush=True)
+    plan.close()
+
+if __name__ == "__main__":
+    cfgs = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]] or [(30, 72, 1), (30, 72, 30), (120, 72, 30)]
+    for c in cfgs:
+        run(*c)
