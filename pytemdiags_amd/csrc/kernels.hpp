@@ -80,13 +80,17 @@ __device__ __forceinline__ int uniform_wave() {
   return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // SGPR: addresses stay scalar
 }
 
-__device__ __forceinline__ bool wave_work(int wave4, int ndt, int nsplit, int& split, int& dt) {
+// workgroup-work decomposition shared by the sweeps: work id -> (split over chunks, quad of
+// d-tiles).  The 4 (x2) waves of a workgroup walk the same chunk range in lockstep (one barrier
+// per step) and share its Y0 blocks through LDS.  Workgroups are dealt to XCDs round-robin
+// (blockIdx % 8); remapping so that each XCD owns a contiguous run of work ids keeps the quads of
+// one chunk range (which stream the same Y0 blocks) behind one L2.
+__device__ __forceinline__ bool wg_work(int ndq, int nsplit, int& split, int& dq) {
   const int cpx = gridDim.x >> 3;
   const int w = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
-  const int64_t id = (int64_t)w * 4 + wave4;
-  if (id >= (int64_t)ndt * nsplit) return false;
-  split = (int)(id / ndt);
-  dt = (int)(id % ndt);
+  if (w >= ndq * nsplit) return false;
+  split = w / ndq;
+  dq = w % ndq;
   return true;
 }
 
@@ -104,13 +108,20 @@ __global__ void __launch_bounds__(256, 2)
 project_kernel(FieldPtrs<NF> fp, int64_t N, int64_t D, int K, const double* __restrict__ yblk,
                int64_t nchunk, const double* __restrict__ colscale, int sfield,
                double* __restrict__ partial, int nsplit, int ndt) {
-  int split, dt;
-  if (!wave_work(uniform_wave(), ndt, nsplit, split, dt)) return;
-  const int lane = threadIdx.x & 63;
+  // Y0 blocks of one chunk (4 groups x TB blocks x 16), double buffered.  They come through LDS
+  // rather than straight into registers because vector loads retire in order: an operand load
+  // issued every few MFMAs would make every wait also wait for the youngest HBM loads of X.
+  __shared__ double ystage[2][4 * TB * 16];
+  int split, dq;
+  if (!wg_work((ndt + 3) >> 2, nsplit, split, dq)) return;
+  const int wave = uniform_wave();
+  const int tid = threadIdx.x, lane = tid & 63;
   const int c = lane & 15, g = lane >> 4;
+  const int dt = dq * 4 + wave;
+  const bool active = dt < ndt;                        // ragged last quad: helper waves only stage
   const int64_t d = (int64_t)dt * 16 + c;
-  const bool dvalid = d < D;
-  const int64_t dcl = dvalid ? d : D - 1;
+  const bool dvalid = active && d < D;
+  const int64_t dcl = d < D ? d : D - 1;
   const int c0 = (int)(nchunk * split / nsplit), c1 = (int)(nchunk * (split + 1) / nsplit);   // uniform
 
   // addressing: wave-uniform base (SGPR) + one 32-bit lane offset
@@ -126,8 +137,10 @@ project_kernel(FieldPtrs<NF> fp, int64_t N, int64_t D, int K, const double* __re
 #pragma unroll
     for (int t = 0; t < TB; ++t) acc[f][t] = 0.0;
 
+  constexpr int YE = 4 * TB * 16;            // doubles of Y0 blocks per chunk
+  constexpr int YJ = (YE + 255) / 256;       // staging loads per thread
   T xn[NF][4];
-  double yn[TB];
+  double ys[YJ];
   auto load_x = [&](int chunk, int ti) {
     const int64_t gb = (int64_t)chunk * 16 + ti * 4;   // first row of the group (uniform)
     if (gb + 4 <= N) {
@@ -140,29 +153,39 @@ project_kernel(FieldPtrs<NF> fp, int64_t N, int64_t D, int K, const double* __re
       for (int f = 0; f < NF; ++f) xn[f][ti] = reinterpret_cast<const T*>(fp.p[f])[row * D + dcl];
     }
   };
-  // yblk is padded by one chunk of zero blocks, so running one group ahead never leaves it
-  auto load_y = [&](int64_t group, int t) { yn[t] = (yblk + (group * TB + t) * 16)[yoff]; };
+  auto load_ys = [&](int chunk) {             // yblk is padded: tid + 256 j never leaves it
+#pragma unroll
+    for (int j = 0; j < YJ; ++j) ys[j] = (yblk + (int64_t)chunk * YE)[tid + 256 * j];
+  };
 
   if (c0 < c1) {
+    load_ys(c0);
+    if (active) {
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti) load_x(c0, ti);
-#pragma unroll
-    for (int t = 0; t < TB; ++t) load_y((int64_t)c0 * 4, t);
+      for (int ti = 0; ti < 4; ++ti) load_x(c0, ti);
+    }
   }
   for (int chunk = c0; chunk < c1; ++chunk) {
+    double* yst = ystage[(chunk - c0) & 1];
+#pragma unroll
+    for (int j = 0; j < YJ; ++j)
+      if (tid + 256 * j < YE) yst[tid + 256 * j] = ys[j];
+    __syncthreads();
     const bool more = chunk + 1 < c1;
+    if (more) load_ys(chunk + 1);
+    if (active) {
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti) {
-      double xs[NF];
+      for (int ti = 0; ti < 4; ++ti) {
+        double xs[NF];
 #pragma unroll
-      for (int f = 0; f < NF; ++f) xs[f] = (double)xn[f][ti] * sc[f];
-      if (more) load_x(chunk + 1, ti);
+        for (int f = 0; f < NF; ++f) xs[f] = (double)xn[f][ti] * sc[f];
+        if (more) load_x(chunk + 1, ti);
 #pragma unroll
-      for (int t = 0; t < TB; ++t) {
-        const double ya = yn[t];
-        load_y((int64_t)chunk * 4 + ti + 1, t);
+        for (int t = 0; t < TB; ++t) {
+          const double ya = yst[(ti * TB + t) * 16 + yoff];
 #pragma unroll
-        for (int f = 0; f < NF; ++f) acc[f][t] = TEMX_MFMA4(ya, xs[f], acc[f][t]);
+          for (int f = 0; f < NF; ++f) acc[f][t] = TEMX_MFMA4(ya, xs[f], acc[f][t]);
+        }
       }
     }
   }
@@ -251,62 +274,52 @@ solve_kernel(const double* __restrict__ B, int K, int K4, int M, int64_t D,
 // ------------------------------------------------------------------------------------------------
 constexpr int EDDY_GR = 2;   // groups (of 4 columns) per eddy step: 8 columns x 16 (lev,time)
 
-// offset (in doubles, relative to the step's first block) of A operand m of an eddy step:
-// m < GR*TB: reconstruction (s = m/GR, ti = m%GR); else projection (ti, tl); m >= 2*GR*TB rolls
-// into the next step (the blocked array is padded, so the last step may run ahead harmlessly).
-template <int TB>
-__device__ __forceinline__ constexpr int y_operand_off(int m) {
-  constexpr int GR = EDDY_GR;
-  int roll = 0;
-  if (m >= 2 * GR * TB) {
-    m -= 2 * GR * TB;
-    roll = GR * TB * 16;
-  }
-  if (m < GR * TB) return roll + ((m % GR) * TB + (m / GR)) * 16;
-  const int mm = m - GR * TB;
-  return roll + ((mm / TB) * TB + (mm % TB)) * 16;
-}
-template <int TB>
-__device__ __forceinline__ constexpr bool y_operand_is_recon(int m) {
-  constexpr int GR = EDDY_GR;
-  if (m >= 2 * GR * TB) m -= 2 * GR * TB;
-  return m < GR * TB;
-}
-
 template <typename T, int TB, int MODE>
 __global__ void __launch_bounds__(512, 2)
-eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restrict__ yblk_r,
-            const double* __restrict__ yblk_p, int64_t nchunk, const double* __restrict__ colscale,
+eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restrict__ yblk,
+            int64_t nchunk, const double* __restrict__ colscale,
             const double* __restrict__ C, double* __restrict__ partial, int nsplit, int ndt,
             EddyOut eo) {
+  // LDS: [4 d-tiles][4 fields][TB][64] coefficient slabs, then per half, double buffered, the Y0
+  // blocks of one step (GR x TB x 16), read by the reconstruction as A[column][harmonic] and by
+  // the projection as A[harmonic][column].  (TEMDiagnostics never uses the weights mode of the
+  // averager, tem_diagnostics.py:243-246, so one unscaled copy serves both.)
   extern __shared__ double lds[];
   constexpr int GR = EDDY_GR;
+  constexpr int YE = GR * TB * 16;           // doubles of Y0 blocks per step
+  constexpr int YJ = (YE + 255) / 256;       // staging loads per thread (256 threads per half)
+  int split, dq;
+  if (!wg_work((ndt + 3) >> 2, nsplit, split, dq)) return;
   const int wave = uniform_wave(), lane = threadIdx.x & 63;
   const int w4 = wave & 3, half = wave >> 2;
-  int split, dt;
-  if (!wave_work(w4, ndt, nsplit, split, dt)) return;
+  const int tid = threadIdx.x & 255;         // thread index inside the half
   const int c = lane & 15, g = lane >> 4;
+  const int dt = dq * 4 + w4;
+  const bool active = dt < ndt;
   const int64_t d = (int64_t)dt * 16 + c;
-  const bool dvalid = d < D;
-  const int64_t dcl = dvalid ? d : D - 1;
+  const bool dvalid = active && d < D;
+  const int64_t dcl = d < D ? d : D - 1;
   const int64_t nstep = nchunk * (4 / GR);
   const int s0 = (int)(nstep * split / nsplit), s1 = (int)(nstep * (split + 1) / nsplit);
   const int sm = s0 + (s1 - s0 + 1) / 2;
   const int c0 = half ? sm : s0, c1 = half ? s1 : sm;   // uniform (SGPR)
+  const int nmax = sm - s0;                              // first half is never the shorter one
 
-  // coefficient B operands: cb[f][s][lane] = C_f[4 s + g][d]
-  double* cb = lds + (size_t)w4 * (4 * TB * 64) + lane;
+  // coefficient B operands: cb[f][s][lane] = C_f[4 s + g][d]; both halves write identical values
+  {
+    double* cb = lds + (size_t)w4 * (4 * TB * 64) + lane;
 #pragma unroll
-  for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < 4; ++f)
 #pragma unroll
-    for (int s = 0; s < TB; ++s) cb[(f * TB + s) * 64] = C[((int64_t)f * 4 * TB + 4 * s + g) * D + dcl];
-
+      for (int s = 0; s < TB; ++s) cb[(f * TB + s) * 64] = C[((int64_t)f * 4 * TB + 4 * s + g) * D + dcl];
+  }
   int cbi = w4 * (4 * TB * 64) + lane;   // index of this lane's first slab element in lds[]
+  double* ystage = lds + 4 * 4 * TB * 64 + half * (2 * YE);   // [buf][YE]
+
   const double sth = colscale != nullptr ? colscale[dcl] : 1.0;
   const uint32_t loff = (uint32_t)(g * D + dcl);
   const uint32_t aoff_r = (uint32_t)((lane & 3) * 4 + g);   // reconstruction A[i -> column][k -> harmonic]
   const uint32_t aoff_p = (uint32_t)(g * 4 + (lane & 3));   // projection     A[i -> harmonic][k -> column]
-  // (the reconstruction always uses the unscaled Y0; yblk_p differs only in weights mode)
 
   double acc[3][TB];
 #pragma unroll
@@ -315,7 +328,7 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
     for (int t = 0; t < TB; ++t) acc[q][t] = 0.0;
 
   T xn[4][GR];
-  double ring[TB];
+  double ys[YJ];
   auto load_x = [&](int step) {
 #pragma unroll
     for (int ti = 0; ti < GR; ++ti) {
@@ -331,17 +344,31 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
       }
     }
   };
-#define TEMX_YOP(step_, m_)                                                                        \
-  (y_operand_is_recon<TB>(m_)                                                                      \
-       ? (yblk_r + (int64_t)(step_) * (GR * TB * 16) + y_operand_off<TB>(m_))[aoff_r]              \
-       : (yblk_p + (int64_t)(step_) * (GR * TB * 16) + y_operand_off<TB>(m_))[aoff_p])
+  auto load_ys = [&](int step) {              // the blocked arrays are padded by one chunk
+#pragma unroll
+    for (int j = 0; j < YJ; ++j) ys[j] = (yblk + (int64_t)step * YE)[tid + 256 * j];
+  };
 
   if (c0 < c1) {
-    load_x(c0);
-#pragma unroll
-    for (int m = 0; m < TB; ++m) ring[m] = TEMX_YOP(c0, m);
+    load_ys(c0);
+    if (active) load_x(c0);
   }
-  for (int step = c0; step < c1; ++step) {
+  // both halves run the same number of barrier rounds (the second half may idle in the last one)
+  for (int it = 0; it < nmax; ++it) {
+    const int step = c0 + it;
+    const bool live = step < c1;
+    double* yst = ystage + (it & 1) * YE;
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < YJ; ++j)
+        if (tid + 256 * j < YE) yst[tid + 256 * j] = ys[j];
+    }
+    __syncthreads();
+    if (!live) continue;
+    const bool more = step + 1 < c1;
+    if (more) load_ys(step + 1);
+    if (!active) continue;
+
     double xs[4][GR];
 #pragma unroll
     for (int f = 0; f < 4; ++f)
@@ -349,7 +376,7 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
       for (int ti = 0; ti < GR; ++ti) xs[f][ti] = (double)xn[f][ti];
 #pragma unroll
     for (int ti = 0; ti < GR; ++ti) xs[2][ti] *= sth;
-    if (step + 1 < c1) load_x(step + 1);
+    if (more) load_x(step + 1);
 
     // The slab is loop invariant: without this, hipcc hoists all 4*TB LDS reads out of the loop
     // into 8*TB registers and spills.  Laundering the index keeps them as in-loop ds_reads.
@@ -362,23 +389,14 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
     for (int f = 0; f < 4; ++f)
 #pragma unroll
       for (int ti = 0; ti < GR; ++ti) rec[f][ti] = 0.0;
-    double cbv[4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) cbv[f] = cbr[(f * TB) * 64];
 #pragma unroll
     for (int s = 0; s < TB; ++s) {
       double cbc[4];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) cbc[f] = cbv[f];
-      if (s + 1 < TB) {
-#pragma unroll
-        for (int f = 0; f < 4; ++f) cbv[f] = cbr[(f * TB + s + 1) * 64];
-      }
+      for (int f = 0; f < 4; ++f) cbc[f] = cbr[(f * TB + s) * 64];
 #pragma unroll
       for (int ti = 0; ti < GR; ++ti) {
-        const int m = s * GR + ti;
-        const double ya = ring[m % TB];
-        ring[m % TB] = TEMX_YOP(step, m + TB);
+        const double ya = yst[(ti * TB + s) * 16 + aoff_r];
 #pragma unroll
         for (int f = 0; f < 4; ++f) rec[f][ti] = TEMX_MFMA4(ya, cbc[f], rec[f][ti]);
       }
@@ -413,14 +431,11 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
     for (int ti = 0; ti < GR; ++ti)
 #pragma unroll
       for (int t = 0; t < TB; ++t) {
-        const int m = GR * TB + ti * TB + t;
-        const double ya = ring[m % TB];
-        ring[m % TB] = TEMX_YOP(step, m + TB);
+        const double ya = yst[(ti * TB + t) * 16 + aoff_p];
 #pragma unroll
         for (int q = 0; q < 3; ++q) acc[q][t] = TEMX_MFMA4(ya, p[q][ti], acc[q][t]);
       }
   }
-#undef TEMX_YOP
 
   if (dvalid && partial != nullptr) {
     const int64_t slab = (int64_t)split * 2 + half;
@@ -441,9 +456,11 @@ __global__ void __launch_bounds__(256, 2)
 recon_kernel(int64_t N, int64_t D, const double* __restrict__ yblk, int64_t nchunk,
              const double* __restrict__ C, double* __restrict__ out, int nsplit, int ndt) {
   extern __shared__ double lds[];
-  int split, dt;
+  int split, dq;
+  if (!wg_work((ndt + 3) >> 2, nsplit, split, dq)) return;
   const int wave = uniform_wave();
-  if (!wave_work(wave, ndt, nsplit, split, dt)) return;
+  const int dt = dq * 4 + wave;
+  if (dt >= ndt) return;
   const int lane = threadIdx.x & 63;
   const int c = lane & 15, g = lane >> 4;
   const int64_t d = (int64_t)dt * 16 + c;

@@ -112,23 +112,23 @@ static int upload(DevBuf& b, const void* src, size_t bytes) {
 static Split choose_split(int64_t D, int64_t nchunk, int slots) {
   Split s;
   s.ndt = (int)((D + 15) / 16);
+  const int ndq = (s.ndt + 3) / 4;            // a workgroup owns 4 consecutive d-tiles
   int64_t maxsplit = std::max<int64_t>(1, nchunk / 4);
-  maxsplit = std::min<int64_t>(maxsplit, std::max<int64_t>(1, (int64_t)16 * slots / s.ndt + 1));
+  maxsplit = std::min<int64_t>(maxsplit, std::max<int64_t>(1, (int64_t)4 * slots / ndq + 1));
   maxsplit = std::min<int64_t>(maxsplit, 4096);
   double best = -1.0;
   int bestn = 1;
   for (int n = 1; n <= maxsplit; ++n) {
-    const int64_t waves = (int64_t)s.ndt * n;
-    const int64_t nwg = (waves + 3) / 4;
+    const int64_t nwg = (int64_t)ndq * n;
     const int64_t rounds = (nwg + slots - 1) / slots;
-    const double eff = (double)waves / (double)(rounds * slots * 4);
+    const double eff = (double)nwg / (double)(rounds * slots);
     if (eff > best * 1.02) {
       best = eff;
       bestn = n;
     }
   }
   s.nsplit = bestn;
-  const int64_t nwg = ((int64_t)s.ndt * s.nsplit + 3) / 4;
+  const int64_t nwg = (int64_t)ndq * s.nsplit;
   s.grid = (int)(((nwg + 7) / 8) * 8);
   return s;
 }
@@ -201,12 +201,11 @@ static int launch_eddy_t(temx_plan* pl, const FieldPtrs<4>& fp, double* partial,
 #define TEMX_LE(TBv)                                                                                  \
   do {                                                                                                \
     auto kern = eddy_kernel<T, TBv, MODE>;                                                            \
-    const size_t lds = (size_t)4 * 4 * TBv * 64 * sizeof(double);                                     \
+    const size_t lds = ((size_t)4 * 4 * TBv * 64 + 2 * 2 * EDDY_GR * TBv * 16) * sizeof(double);      \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
     hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->N, pl->D, pl->K, pl->yblk.d(),             \
-                       pl->yproj_ptr(), pl->nchunk, pl->colscale.d(), pl->C4.d(), partial, sp.nsplit, \
-                       sp.ndt, eo);                                                                   \
+                       pl->nchunk, pl->colscale.d(), pl->C4.d(), partial, sp.nsplit, sp.ndt, eo);     \
   } while (0)
   switch (pl->TB) {
     case 4: TEMX_LE(4); break;
