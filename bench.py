@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- grid-points/s through the full TEM pipeline on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ne120x72x30] [--shard time|ncol]
+
+A *step* is one pass of the whole hot path (theta, 7 projections, 4 native reconstructions,
+eddy products, zonal apply, fused epilogue -> the ten GM16 Table-A1 outputs) over synthetic
+fields already resident in HBM.  Plan build (basis + Gram + Cholesky) is timed separately.
+
+N = 1   : the workload BASELINE.json's target is quoted on, ne120 (777602 columns) x 72 lev x 30
+          snapshots, fp64, on one GPU.
+N > 1   : launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`,
+          one rank per GPU over RCCL.  Default `--shard time`: every rank holds its own block of
+          30 snapshots of the same grid (weak scaling, no data-path collective).  `--shard ncol`:
+          the one ne120x72x30 job is split by columns with an all-reduce of the zonal sums
+          (strong scaling).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+K_HARM = 51                      # L = 50 (tem_diagnostics.py:33)
+FLOPS_PER_PT = 11 * 2 * K_HARM   # 7 projections + 4 reconstructions
+PEAK_F64_TFLOPS = 78.6           # MI355X FP64 matrix = vector peak (public spec)
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse_workload(s):
+    ne, nlev, nt = s.lower().replace("ne", "").split("x")
+    return int(ne), int(nlev), int(nt)
+
+
+def zm_lat(dlat=1.0):
+    e = np.arange(-90, 90 + dlat, dlat)
+    return (e[1:] + e[:-1]) / 2
+
+
+def cpu_baseline_and_parity(plan_factory, lat, lon, plev, nt_s, device):
+    """Time the CPU oracle (numpy port, factorised association) on a bounded sample of the same
+    workload -- the same grid and levels, nt_s snapshots -- and check the GPU result on exactly
+    that sample against it."""
+    from oracle import tem_oracle as orc
+    from pytemdiags_amd import engine, _lib
+    f = engine.synth_fields(device, lat, lon, plev, nt_s, t0=0, dtype=torch.float64, seed=0)
+    host = [x.cpu().numpy() for x in f]
+    t0 = time.perf_counter()
+    o = orc.TEMOracle(*host, lat, plev, mode="factorised")
+    ref = o.results()
+    t_cpu = time.perf_counter() - t0
+    plan = plan_factory()
+    plan.set_tem(len(plev), nt_s, plev * 100)
+    res, _ = plan.tem_run(*f)
+    bad = plan.status()
+    res = res.cpu().numpy()
+    err = 0.0
+    for i, n in enumerate(_lib.RESULT_NAMES):
+        err = max(err, float(np.max(np.abs(res[i] - ref[n])) / np.max(np.abs(ref[n]))))
+    plan.close()
+    pts = lat.size * len(plev) * nt_s
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    return {"value": pts / t_cpu, "unit": "grid-points/s", "cores": cores, "kind": "port",
+            "sample": "ne%d grid (%d cols) x %d lev x %d of the snapshots, oracle/tem_oracle.py "
+                      "factorised numpy restatement, %.1f s" % (0, lat.size, len(plev), nt_s, t_cpu)}, err, bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="ne120x72x30")
+    ap.add_argument("--shard", choices=["time", "ncol"], default="time")
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-nt", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from pytemdiags_amd import engine, sharding, synth
+
+    ne, nlev, nt = parse_workload(args.workload)
+    lat, lon = synth.cubed_sphere_gll(ne)
+    plev = synth.pressure_levels(nlev)
+    lat_zm = zm_lat(1.0)
+    tdtype = torch.float64 if args.dtype == "f64" else torch.float32
+    ncol = lat.size
+
+    # ---- shard ----
+    if args.shard == "ncol" and world > 1:
+        i0, i1 = sharding.shard_bounds(ncol, world, rank)
+        lat_l, lon_l, t0_l, nt_l = lat[i0:i1], lon[i0:i1], 0, nt
+        scaling, pts_job = "strong", ncol * nlev * nt
+    else:
+        lat_l, lon_l, t0_l, nt_l = lat, lon, rank * nt, nt
+        scaling, pts_job = "weak", ncol * nlev * nt * world
+
+    # ---- plan (timed separately; the reference amortises it through its map cache) ----
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    plan = engine.Plan(lat_l, lat_zm, K_HARM - 1, device=local_rank, defer_finalize=(args.shard == "ncol" and world > 1))
+    if args.shard == "ncol" and world > 1:
+        runner = sharding.NcolShardedTEM(plan)
+    plan.set_tem(nlev, nt_l, plev * 100)
+    torch.cuda.synchronize()
+    plan_s = time.perf_counter() - t0
+
+    fields = engine.synth_fields(local_rank, lat_l, lon_l, plev, nt_l, t0=t0_l, dtype=tdtype, seed=0)
+    out = plan._alloc_results(False)
+
+    if args.shard == "ncol" and world > 1:
+        def step():
+            return runner.run(*fields)
+    else:
+        def step():
+            return plan.tem_run(*fields, out=out)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    plan.kernel_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    nonfinite = plan.status()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    proj_ms, nproj = plan.kernel_timing_read(0)
+    eddy_ms, neddy = plan.kernel_timing_read(1)
+    plan.kernel_timing(False)
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = pts_job * args.steps / elapsed
+    pts_rank = lat_l.size * nlev * nt_l
+    esize = 8 if args.dtype == "f64" else 4
+
+    rec = {
+        "metric": "grid-points/sec through full TEM pipeline (ncol*nlev*nt)",
+        "value": value, "unit": "grid-points/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "ne%d (%d cols) x %d lev x %d snapshots per %s, L=50, 1-degree zonal grid (M=180), "
+                               "ten GM16 Table-A1 outputs" % (ne, ncol, nlev, nt, "GPU" if scaling == "weak" else "job"),
+                   "shard": args.shard if world > 1 else "none", "ncol": int(ncol), "nlev": nlev, "nt": nt},
+        "plan_build_s": plan_s,
+        "pipeline_frac_of_fp64_roofline": value / world / (PEAK_F64_TFLOPS * 1e12 / FLOPS_PER_PT),
+        "nonfinite": bool(nonfinite),
+    }
+    if neddy:
+        ach = 7 * 2 * K_HARM * pts_rank / (eddy_ms * 1e-3) / 1e12
+        rec["roofline"] = {"kernel": "eddy_kernel (4 reconstructions + eddy products + 3 projections)",
+                           "bound": "mfma", "achieved": ach, "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / PEAK_F64_TFLOPS, "traffic": None, "avg_launch_ms": eddy_ms,
+                           "launches": neddy,
+                           "algorithmic": "7*2*51 flop per grid point x %d points per launch" % pts_rank}
+        tr = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tr):
+            try:
+                j = json.load(open(tr))
+                if j.get("workload") == args.workload and j.get("dtype") == args.dtype:
+                    rec["roofline"]["traffic"] = j.get("eddy_kernel_hbm_bytes_per_launch")
+            except Exception:
+                pass
+    if nproj:
+        gbs = 4 * esize * pts_rank / (proj_ms * 1e-3) / 1e9
+        rec["roofline_project"] = {"kernel": "project_kernel (theta + 4 projections)", "bound": "hbm",
+                                   "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": gbs / PEAK_HBM_GBS, "avg_launch_ms": proj_ms,
+                                   "mfma_tflops": 4 * 2 * K_HARM * pts_rank / (proj_ms * 1e-3) / 1e12}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        del fields
+        torch.cuda.empty_cache()
+        cb, err, bad = cpu_baseline_and_parity(lambda: engine.Plan(lat, lat_zm, K_HARM - 1, device=local_rank),
+                                               lat, lon, plev, args.cpu_sample_nt, local_rank)
+        cb["sample"] = cb["sample"].replace("ne0", "ne%d" % ne)
+        rec["cpu_baseline"] = cb
+        rec["parity_vs_oracle_on_sample"] = {"max_field_normalised_err": err, "tolerance": 1e-10,
+                                            "ok": bool(err <= 1e-10 and not bad)}
+    plan.close()
+    if rank == 0:
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,97 @@
+"""Multi-GPU sharding of the TEM pipeline: one process per GPU, torch.distributed (RCCL on ROCm).
+
+Two ways the path shards:
+
+* **time sharding** -- the columns of the (N x D) operand are independent, so each rank takes a
+  contiguous block of time snapshots with a replicated plan.  No collective on the data path.
+* **ncol sharding** -- rows split in contiguous blocks; the only cross-row reduction is the
+  projection ``Y0^T A``, so each rank computes partial sums over its rows and the ranks
+  all-reduce (i) the K x K Gram matrix once at plan build, (ii) the [4][K][D] sums of
+  (u, v, theta, omega) and (iii) the [3][K][D] sums of the eddy products -- one fused message
+  each.  Every rank then solves the K x K system and evaluates the (tiny) zonal-grid epilogue
+  redundantly.
+
+The driver below only sequences stages and collectives; the numerics live behind a *backend*
+with the ``engine.Plan`` stage interface (``matrix``, ``finalize``, ``tem_stage1/2/3``).  On
+the GPU the backend is ``engine.Plan``; the world_size-2 gloo tests drive the same code with a
+CPU stand-in built on the oracle.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+MAT_GRAM = 2
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous near-equal blocks: the first ``n % world`` ranks get one extra element."""
+    base, extra = divmod(int(n), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def _world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group)
+    return 1
+
+
+def allreduce_sum_(t, group=None):
+    """In-place sum over ranks (RCCL for device tensors, gloo for CPU tensors); no-op at world 1."""
+    if _world(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+class NcolShardedTEM:
+    """TEM pipeline over this rank's block of native columns.
+
+    ``backend`` is a plan created over the rank's own latitudes with ``defer_finalize=True``.
+    """
+
+    def __init__(self, backend, group=None):
+        self.backend = backend
+        self.group = group
+        G = backend.matrix(MAT_GRAM)
+        allreduce_sum_(G, group)                       # (i) Gram matrix, K x K, once
+        backend.finalize(G.detach().cpu().numpy())
+
+    def run(self, ua, va, ta, wap, want_zonal=False):
+        be = self.backend
+        B4 = be.tem_stage1(ua, va, ta, wap)
+        allreduce_sum_(B4, self.group)                 # (ii) [4][K][D] zonal sums, one message
+        B3 = be.tem_stage2(ua, va, ta, wap, B4)
+        allreduce_sum_(B3, self.group)                 # (iii) [3][K][D] flux sums, one message
+        return be.tem_stage3(B3, want_zonal)
+
+
+class TimeShardedTEM:
+    """Replicated plan, private time block per rank; outputs stay sharded along time."""
+
+    def __init__(self, backend, nt_total, rank=None, world=None, group=None):
+        self.backend = backend
+        self.world = _world(group) if world is None else world
+        self.rank = (dist.get_rank(group) if self.world > 1 and rank is None else (rank or 0))
+        self.t0, self.t1 = shard_bounds(nt_total, self.world, self.rank)
+
+    def run(self, ua, va, ta, wap, want_zonal=False):
+        return self.backend.tem_run(ua, va, ta, wap, want_zonal)
+
+
+def gather_time(res, group=None):
+    """Concatenate time-sharded results [R][M][nlev][nt_local] along time on every rank
+    (ragged blocks are padded to the longest one for the collective, then trimmed)."""
+    w = _world(group)
+    if w == 1:
+        return res
+    n = torch.tensor([res.shape[-1]], dtype=torch.int64, device=res.device)
+    sizes = [torch.zeros_like(n) for _ in range(w)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    nmax = max(sizes)
+    pad = torch.zeros(res.shape[:-1] + (nmax,), dtype=res.dtype, device=res.device)
+    pad[..., :res.shape[-1]] = res
+    outs = [torch.empty_like(pad) for _ in range(w)]
+    dist.all_gather(outs, pad, group=group)
+    return torch.cat([o[..., :k] for o, k in zip(outs, sizes)], dim=-1)
