@@ -245,6 +245,29 @@ class TEMOracle:
         self.upwapp = self.up * self.wapp;    self.upwappb = zm(self.upwapp)
         self.vptp = self.vp * self.thetap;    self.vptpb = zm(self.vptp)
 
+        self._derivatives()
+
+    @classmethod
+    def from_zonal_means(cls, zonal, plev, va_dtype=np.float64, ua_dtype=np.float64, wap_dtype=np.float64,
+                         p0=P0, zm_dlat=1, zm_pole_points=False):
+        """Epilogue only: build the derivative / diagnostic part from the seven zonal means
+        (dict with ub vb thetab wapb upvpb upwappb vptpb, each (M, nlev, nt)).  Used by the
+        sharding tests, where the zonal means come out of an all-reduce."""
+        self = cls.__new__(cls)
+        self.plev = np.asarray(plev)
+        self.p0, self.p = p0, self.plev * 100
+        self.lat = zm_latitudes(zm_dlat, zm_pole_points)
+        self.f = (2 * Om * np.sin(self.lat * np.pi / 180))[:, None, None]
+        self.coslat = np.cos(self.lat * np.pi / 180)
+        for n in ("ub", "vb", "thetab", "wapb", "upvpb", "upwappb", "vptpb"):
+            setattr(self, n, np.asarray(zonal[n]))
+        self.ua = np.empty(0, dtype=ua_dtype)
+        self.va = np.empty(0, dtype=va_dtype)
+        self.wap = np.empty(0, dtype=wap_dtype)
+        self._derivatives()
+        return self
+
+    def _derivatives(self):
         # derivatives  (:579-599)
         latr = np.deg2rad(self.lat)
         self.dub_dp = p_gradient(self.ub, self.p)

@@ -1,0 +1,330 @@
+"""Drop-in front end for ``PyTEMDiags.TEMDiagnostics`` (reference: PyTEMDiags/tem_diagnostics.py).
+
+Same constructor, methods, properties and error behaviour.  All numerics -- potential
+temperature, the 7 + 4 zonal means, eddy products, p / lat derivatives, psi, the cumulative
+pressure integral and the ten GM16 Table-A1 diagnostics -- run on the MI355X in the HIP engine
+(libtemx.so); this module only validates, reshapes and labels.
+
+Input kinds (the output kind follows the input kind):
+  * labelled arrays -- ``xarray.DataArray`` when xarray is importable, or anything with
+    ``.dims`` / ``.values`` and a ``plev`` coordinate (``containers.LabeledArray``);
+  * raw ``numpy.ndarray`` / ``torch.Tensor`` laid out as ``dims`` (default
+    ``(ncol, plev, time)``) with explicit ``plev=`` [hPa] and optional ``time=``.
+"""
+from __future__ import annotations
+
+import os
+import warnings
+
+import numpy as np
+
+from . import _lib, containers
+from .constants import P0, Om
+from .sph_zonal_mean import sph_zonal_averager
+
+DEFAULT_DIMS = {"horz": "ncol", "vert": "plev", "time": "time"}        # tem_diagnostics.py:25
+
+# dtype each stored quantity has in the reference when the inputs are not fp64:
+# theta is promoted to fp64 by the fp64 pressure einsum (tem_diagnostics.py:498); everything
+# downstream of theta, of cos(lat) products or of p_integral is fp64; the rest keeps the input dtype.
+_F64_ALWAYS = {"thetab", "vptpb", "dthetab_dp", "ubcoslat", "dubcoslat_dlat", "psi", "psicoslat",
+               "dpsicoslat_dlat", "dpsi_dp", "int_vbdp", "thetap", "vptp", "theta"}
+
+
+class TEMDiagnostics:
+    def __init__(self, ua, va, ta, wap, lat_native, q=None, p0=P0, zm_dlat=1, L=50,
+                 dim_names=DEFAULT_DIMS, grid_name=None, zm_grid_name=None, map_save_dest=None,
+                 overwrite_map=False, zm_pole_points=False, debug_level=1, logfile=None,
+                 *, plev=None, time=None, dims=None, device=None):
+        # ---- arguments (tem_diagnostics.py:217-236) ----
+        self.p0 = p0
+        self.q = q
+        self.ntrac = None
+        self.lat_native = lat_native
+        self.L = L
+        self.zm_dlat = zm_dlat
+        self.dim_names = dim_names
+        self.zm_pole_points = zm_pole_points
+        self.grid_name = grid_name
+        self.zm_grid_name = zm_grid_name
+        self.map_save_dest = map_save_dest
+        self.overwrite_map = overwrite_map
+        self.debug_level = debug_level
+        self.logfile = logfile
+        self._device = 0 if device is None else device
+        self._raw_dims = dims
+        self._raw_plev, self._raw_time = plev, time
+        self._in = {"ua": ua, "va": va, "ta": ta, "wap": wap}
+
+        self._config_dims()
+
+        # ---- zonal averaging object (tem_diagnostics.py:243-249) ----
+        self.ZM = sph_zonal_averager(self._lat_native_np, self._lat_zm, self.L, grid_name=grid_name,
+                                     grid_out_name=zm_grid_name, save_dest=map_save_dest,
+                                     debug=debug_level > 1, overwrite=overwrite_map, device=self._device)
+        if self.ZM.Y0 is None or self.ZM.Y0p is None:
+            self.ZM.sph_compute_matrices(overwrite=overwrite_map)
+        self._zonal_mean = self.ZM.sph_zonal_mean
+
+        # ---- the whole numeric pipeline: one engine call (tem_diagnostics.py:252-259) ----
+        plan = self.ZM._plan
+        plan.set_tem(self.NLEV, self.NT, self._p_np, float(self.p0))
+        self._res, self._zon = plan.tem_run(*self._dev_fields, want_zonal=True)
+        if plan.status():                                   # sph_zonal_mean.py:219-221
+            raise RuntimeError("Variable has nans! Spectral zonal averager cannot handle nans; "
+                               "please replace or remove them")
+        self._eddy = None
+        self._theta = None
+        self._out_file = None
+
+    # ------------------------------------------------------------------------------------------
+    def _config_dims(self):
+        """Validation and reshaping of tem_diagnostics.py:266-405 (host side only)."""
+        import torch
+        self.ncolname = self.dim_names["horz"]
+        self.plevname = self.dim_names["vert"]
+        try:
+            self.timename = self.dim_names["time"]
+        except KeyError:
+            self.timename = DEFAULT_DIMS["time"]
+        self.data_dims = (self.ncolname, self.plevname, self.timename)
+
+        # tracers (tem_diagnostics.py:281-301): Abalos+ 2017 tracer TEM is the next scope row
+        if self.q is not None:
+            ql = self.q if isinstance(self.q, list) else [self.q]
+            if not all(containers.is_labeled(x) for x in ql):
+                raise RuntimeError("tracers q must be passed as an xarray DataArray, or"
+                                   "a list of xarray DataArrays")
+            raise NotImplementedError("tracer TEM (q=...) is not part of this engine yet "
+                                      "(SURVEY.md section 8(f), row 1)")
+        self.ntrac = 0
+        self._q_out_file = []
+
+        lat = self.lat_native
+        self._lat_native_np = np.asarray(lat.values if containers.is_labeled(lat) else
+                                         (lat.detach().cpu().numpy() if hasattr(lat, "detach") else lat),
+                                         dtype=np.float64)
+        nlat = self._lat_native_np.shape[0]
+
+        labeled = [containers.is_labeled(v) for v in self._in.values()]
+        if any(labeled) and not all(labeled):
+            raise RuntimeError("Input data for args ua, va, ta, wap must all be of the same kind")
+        self._kind = "raw"
+        if all(labeled):
+            self._kind = "xarray" if containers.is_xarray(self._in["ua"]) else "labeled"
+
+        vals = {}
+        for var, dat in self._in.items():
+            if self._kind == "raw":
+                if not (isinstance(dat, np.ndarray) or isinstance(dat, torch.Tensor)):
+                    raise RuntimeError("Input data for arg '{}' must be an xarray DataArray".format(var))   # :313
+                ddims = tuple(self._raw_dims) if self._raw_dims is not None else self.data_dims[:dat.ndim]
+                v = dat
+            else:
+                ddims = tuple(dat.dims)
+                v = dat.values
+            if self.ncolname not in ddims:                                                    # :316-318
+                raise RuntimeError("Input data {} does not contain dim {}".format(var, self.ncolname))
+            if v.shape[ddims.index(self.ncolname)] != nlat:                                   # :320-323
+                raise RuntimeError("Dimension {} in variable {} is length {}, but input parameter lat is "
+                                   "length {}; these must match!".format(
+                                       self.ncolname, var, v.shape[ddims.index(self.ncolname)], nlat))
+            if len(ddims) < 2 or len(ddims) > 3:                                              # :326-329
+                raise RuntimeError("Input data has {0} dims, expected either 2 ({1}, {2}) or 3 ({1}, {2}, {3})"
+                                   .format(len(ddims), self.ncolname, self.plevname, self.timename))
+            t = v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))
+            if self.timename not in ddims:                  # 2-D input: add a length-1 time axis (:332-335)
+                t = t.unsqueeze(-1)
+                ddims = ddims + (self.timename,)
+            if self.plevname not in ddims:
+                raise RuntimeError("Input data {} does not contain dim {}".format(var, self.plevname))
+            perm = [ddims.index(n) for n in self.data_dims]                                   # :343-353
+            vals[var] = t.permute(*perm)
+
+        ua = self._in["ua"]
+        # ---- coordinates (tem_diagnostics.py:360-367) ----
+        if self._kind == "raw":
+            if self._raw_plev is None:
+                raise RuntimeError("raw array inputs need plev= (pressure levels in hPa)")
+            plev = np.asarray(self._raw_plev, dtype=np.float64)
+            nt = vals["ua"].shape[2]
+            time = np.asarray(self._raw_time) if self._raw_time is not None else np.arange(nt)
+        else:
+            plev = np.asarray(containers.coord_of(ua, self.plevname), dtype=np.float64)
+            time = containers.coord_of(ua, self.timename) if self.timename in ua.dims else np.zeros(1)
+        self.NCOL, self.NLEV, self.NT = (int(s) for s in vals["ua"].shape)
+        if plev.shape[0] != self.NLEV:
+            raise RuntimeError("plev has {} entries but the data have {} levels".format(plev.shape[0], self.NLEV))
+        for var in ("va", "ta", "wap"):
+            if tuple(vals[var].shape) != tuple(vals["ua"].shape):
+                raise RuntimeError("Input data {} has shape {}, expected {}".format(
+                    var, tuple(vals[var].shape), tuple(vals["ua"].shape)))
+
+        # ---- pressure direction: model top first (tem_diagnostics.py:369-382) ----
+        if plev[0] > plev[-1]:
+            vals = {k: torch.flip(v, dims=(1,)) for k, v in vals.items()}
+            plev = plev[::-1].copy()
+        self.plev = plev
+        self.time = time
+        self.p = self.plev * 100                                                              # :385
+        self._p_np = np.asarray(self.p, dtype=np.float64)
+
+        # ---- zonal-mean latitudes (tem_diagnostics.py:387-398) ----
+        tol = 1e-6
+        assert (180 / self.zm_dlat).is_integer(), "180 must be divisible by dlat_out"
+        self._lat_zm = np.arange(-90, 90 + self.zm_dlat, self.zm_dlat)
+        if self._lat_zm[-1] > 90 + tol:
+            self._lat_zm = self._lat_zm[:-1]
+        if not self.zm_pole_points:
+            self._lat_zm = (self._lat_zm[1:] + self._lat_zm[:-1]) / 2
+        self.ZM_N = len(self._lat_zm)
+        self._f_zm = 2 * Om * np.sin(self._lat_zm * np.pi / 180)                              # :401
+        self._coslat_zm = np.cos(self._lat_zm * np.pi / 180)                                  # :402
+        self.lat, self.coslat = self._lat_zm, self._coslat_zm
+        self.f = self._f_zm[:, np.newaxis, np.newaxis]
+
+        # ---- device residency: contiguous [ncol][plev][time], one dtype ----
+        dts = {v.dtype for v in vals.values()}
+        self._in_dtype = {k: v.dtype for k, v in vals.items()}
+        work = torch.float32 if dts == {torch.float32} else torch.float64
+        dev = torch.device("cuda", int(self._device) if not isinstance(self._device, torch.device)
+                           else (self._device.index or 0))
+        self._torch_out = isinstance(self._in["ua"], torch.Tensor) or (
+            self._kind != "raw" and isinstance(self._in["ua"].values, torch.Tensor))
+        self._dev_fields = [vals[k].to(device=dev, dtype=work).contiguous() for k in ("ua", "va", "ta", "wap")]
+        self.ua, self.va, self.ta, self.wap = self._dev_fields
+
+    # ------------------------------------------------------------------------------------------
+    def _np_dtype(self, var):
+        import torch
+        return {torch.float32: np.float32, torch.float64: np.float64}.get(self._in_dtype[var], np.float64)
+
+    def _wrap(self, t, name, src_var, native=False, force64=False):
+        """Label a device result; cast like the reference's astype."""
+        import torch
+        dt = np.float64 if (force64 or name in _F64_ALWAYS) else self._np_dtype(src_var)
+        tdt = torch.float64 if dt == np.float64 else torch.float32
+        t = t.to(tdt)
+        vals = t if self._torch_out else t.cpu().numpy()
+        if self._kind == "raw":
+            return vals
+        first = self.ncolname if native else "lat"
+        dims = (first, self.plevname, self.timename)
+        coords = {self.plevname: self.plev, self.timename: self.time}
+        if not native:
+            coords["lat"] = self._lat_zm
+        return containers.make_like(self._kind, vals, dims, coords, name)
+
+    def _zonal(self, name, src_var):
+        return self._wrap(self._zon[_lib.ZONAL_NAMES.index(name)], name, src_var)
+
+    def _result(self, name, src_var):
+        return self._wrap(self._res[_lib.RESULT_NAMES.index(name)], name, src_var)
+
+    def _native(self, name, src_var):
+        if self._eddy is None:                        # lazily materialised [ncol][plev][time] fields
+            self._eddy = self.ZM._plan.tem_eddy(*self._dev_fields)
+        return self._wrap(self._eddy[name], name, src_var, native=True)
+
+    # ---- getters (tem_diagnostics.py:412-487) ----
+    ub = property(lambda s: s._zonal("ub", "ua"))
+    vb = property(lambda s: s._zonal("vb", "va"))
+    thetab = property(lambda s: s._zonal("thetab", "ta"))
+    wapb = property(lambda s: s._zonal("wapb", "wap"))
+    up = property(lambda s: s._native("up", "ua"))
+    vp = property(lambda s: s._native("vp", "va"))
+    thetap = property(lambda s: s._native("thetap", "ta"))
+    wapp = property(lambda s: s._native("wapp", "wap"))
+    upvp = property(lambda s: s._native("upvp", "ua"))
+    upwapp = property(lambda s: s._native("upwapp", "ua"))
+    vptp = property(lambda s: s._native("vptp", "va"))
+    upvpb = property(lambda s: s._zonal("upvpb", "ua"))
+    upwappb = property(lambda s: s._zonal("upwappb", "ua"))
+    vptpb = property(lambda s: s._zonal("vptpb", "va"))
+    dub_dp = property(lambda s: s._zonal("dub_dp", "ua"))
+    dthetab_dp = property(lambda s: s._zonal("dthetab_dp", "ta"))
+    ubcoslat = property(lambda s: s._zonal("ubcoslat", "ua"))
+    dubcoslat_dlat = property(lambda s: s._zonal("dubcoslat_dlat", "ua"))
+    psicoslat = property(lambda s: s._zonal("psicoslat", "ta"))
+    dpsicoslat_dlat = property(lambda s: s._zonal("dpsicoslat_dlat", "ta"))
+    int_vbdp = property(lambda s: s._zonal("int_vbdp", "va"))
+    psi = property(lambda s: s._zonal("psi", "ta"))
+    dpsi_dp = property(lambda s: s._zonal("dpsi_dp", "ta"))
+    # tracer getters exist for API parity; there are no tracers (ntrac == 0)
+    qp = qpvp = qpwapp = qb = qpvpb = qpwappb = dqb_dp = qbcoslat = dqbcoslat_dlat = property(lambda s: [])
+
+    @property
+    def theta(self):
+        """theta = T (p0/p)^k (tem_diagnostics.py:498); recovered as thetap + its native zonal mean
+        would cost a sweep, so it is formed from the same per-level scale the engine fuses."""
+        import torch
+        if self._theta is None:
+            from .constants import k
+            scale = torch.as_tensor((float(self.p0) / self._p_np) ** k, device=self._dev_fields[2].device)
+            self._theta = self._dev_fields[2].to(torch.float64) * scale[None, :, None]
+        return self._wrap(self._theta, "THETA", "ta", native=True, force64=True)
+
+    @property
+    def out_file(self):
+        if self._out_file is None:
+            warnings.warn("'out_file' is not set until to_netcdf() is called")
+        return self._out_file
+
+    @property
+    def q_out_file(self):
+        warnings.warn("'q_out_file' is emtpy; no tracers currently present")
+        return self._q_out_file
+
+    # ---- the ten diagnostics (tem_diagnostics.py:615-797), each cast to its input's dtype ----
+    def vtem(self): return self._result("vtem", "va")                  # noqa: E704
+    def omegatem(self): return self._result("omegatem", "wap")         # noqa: E704
+    def wtem(self): return self._result("wtem", "wap")                 # noqa: E704
+    def psitem(self): return self._result("psitem", "va")              # noqa: E704
+    def epfy(self): return self._result("epfy", "ua")                  # noqa: E704
+    def epfz(self): return self._result("epfz", "ua")                  # noqa: E704
+    def epdiv(self): return self._result("epdiv", "ua")                # noqa: E704
+    def utendepfd(self): return self._result("utendepfd", "ua")        # noqa: E704
+    def utendvtem(self): return self._result("utendvtem", "ua")        # noqa: E704
+    def utendwtem(self): return self._result("utendwtem", "ua")        # noqa: E704
+
+    def _no_tracers(self, *a, **k):
+        raise RuntimeError("no tracers present (argument `q` not passed at object construction)")
+    etfy = etfz = etdiv = qtendetfd = qtendvtem = qtendwtem = _no_tracers
+
+    def results(self):
+        return {n: getattr(self, n)() for n in _lib.RESULT_NAMES}
+
+    # ---- I/O (tem_diagnostics.py:995-1041): needs xarray + a NetCDF back end ----
+    def to_netcdf(self, loc=os.getcwd(), prefix=None, include_attrs=False):
+        prefix = "{}_".format(prefix) if prefix is not None else ""
+        filename = "{}TEM_{}_{}_L{}.nc".format(prefix, self.ZM.grid_name, self.ZM.grid_out_name, self.L)
+        self._out_file = "{}/{}".format(loc, filename)
+        try:
+            import xarray as xr
+        except ImportError as e:
+            raise RuntimeError("to_netcdf() needs xarray and a NetCDF back end, which are not installed; "
+                               "use results() and write the arrays yourself") from e
+        out = {n: self._as_xr(getattr(self, n)()) for n in _lib.RESULT_NAMES}
+        if include_attrs:   # (sic) key 'wawpp' as in tem_diagnostics.py:1011
+            names = {"ub": "ub", "up": "up", "vb": "vb", "vp": "vp", "thetab": "thetab", "thetap": "thetap",
+                     "wapb": "wapb", "wawpp": "wapp", "upvp": "upvp", "upvpb": "upvpb", "upwapp": "upwapp",
+                     "upwappb": "upwappb", "vptp": "vptp", "vptpb": "vptpb", "dub_dp": "dub_dp",
+                     "dthetab_dp": "dthetab_dp", "ubcoslat": "ubcoslat", "dubcoslat_dlat": "dubcoslat_dlat",
+                     "psi": "psi", "psicoslat": "psicoslat", "dpsicoslat_dlat": "dpsicoslat_dlat",
+                     "dpsi_dp": "dpsi_dp", "int_vbdp": "int_vbdp"}
+            out = dict({k: self._as_xr(getattr(self, v)) for k, v in names.items()}, **out)
+        xr.Dataset(out).to_netcdf(self._out_file)
+        return self._out_file
+
+    def _as_xr(self, x):
+        import xarray as xr
+        if isinstance(x, xr.DataArray):
+            return x
+        v = x.values if containers.is_labeled(x) else x
+        if hasattr(v, "detach"):
+            v = v.detach().cpu().numpy()
+        dims = x.dims if containers.is_labeled(x) else ("lat", self.plevname, self.timename)
+        return xr.DataArray(v, dims=dims)
+
+    def q_to_netcdf(self, *a, **k):
+        assert self.ntrac > 0, "No tracers to output (argument `q` not passed at object construction)"

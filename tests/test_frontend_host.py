@@ -1,0 +1,90 @@
+"""CPU-only tests: host-side validation of the front end (errors raised before any device work),
+the C-ABI library's exported symbols, and the sharding helpers."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_symbol_of_the_header():
+    from pytemdiags_amd import _lib
+    lib = _lib.load()                                   # raises if libtemx.so is missing / stale
+    header = open(os.path.join(ROOT, "include", "temx.h")).read()
+    declared = set(re.findall(r"\b(temx_[a-z0-9_]+)\s*\(", header))
+    declared.discard("temx_plan")
+    bound = {n for n, _, _ in _lib.SIGNATURES}
+    assert declared == bound, (declared ^ bound)
+    for n in declared:
+        assert hasattr(lib, n), n
+    assert lib.temx_version() >= 100
+    assert isinstance(lib.temx_last_error(), bytes)
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from pytemdiags_amd import _lib
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    lat = (ctypes.c_double * 4)(0, 10, 20, 30)
+    rc = lib.temx_plan_create(ctypes.byref(h), 0, 4, 2, 4, lat, lat, 0)
+    assert rc == -2 and not h.value                      # TEMX_EHIP: no device, no fallback
+    assert b"" != lib.temx_last_error()
+    from pytemdiags_amd import sph_zonal_averager
+    ZM = sph_zonal_averager(np.linspace(-80, 80, 50), np.linspace(-60, 60, 7), 5)
+    with pytest.raises(_lib.TemxError):
+        ZM.sph_compute_matrices()
+
+
+def test_frontend_validation_errors_match_reference():
+    from pytemdiags_amd import TEMDiagnostics, LabeledArray
+    N, nlev, nt = 40, 5, 2
+    lat = np.linspace(-85, 85, N)
+    plev = np.linspace(100, 900, nlev)
+
+    def mk(dims=("ncol", "plev", "time"), shape=(N, nlev, nt)):
+        return LabeledArray(np.ones(shape), dims, {"plev": plev, "time": np.arange(nt)})
+    good = mk()
+    with pytest.raises(RuntimeError, match="does not contain dim"):            # tem_diagnostics.py:316-318
+        TEMDiagnostics(mk(dims=("cells", "plev", "time")), good, good, good, lat, debug_level=0)
+    with pytest.raises(RuntimeError, match="these must match"):               # :320-323
+        TEMDiagnostics(good, good, good, good, lat[:-1], debug_level=0)
+    with pytest.raises(RuntimeError, match="dims"):                            # :326-329
+        TEMDiagnostics(LabeledArray(np.ones((N, nlev, nt, 2)), ("ncol", "plev", "time", "x"), {"plev": plev}),
+                       good, good, good, lat, debug_level=0)
+    with pytest.raises(AssertionError):                                        # :389
+        TEMDiagnostics(good, good, good, good, lat, zm_dlat=7, debug_level=0)
+    with pytest.raises(RuntimeError, match="xarray DataArray"):                # :313
+        TEMDiagnostics([1, 2], [1, 2], [1, 2], [1, 2], lat, plev=plev, debug_level=0)
+    with pytest.raises(RuntimeError, match="tracers"):                          # :294
+        TEMDiagnostics(good, good, good, good, lat, q=[np.ones(3)], debug_level=0)
+    with pytest.raises(NotImplementedError):
+        TEMDiagnostics(good, good, good, good, lat, q=good, debug_level=0)
+
+
+def test_averager_constructor_attributes_without_gpu():
+    from pytemdiags_amd import sph_zonal_averager
+    lat = np.linspace(-89, 89, 120)
+    lat_out = np.arange(-89.5, 90, 1.0)
+    Z = sph_zonal_averager(lat, lat_out, 50, save_dest="/tmp/maps")
+    assert (Z.N, Z.M, Z.L) == (120, 180, 50) and list(Z.l[:3]) == [0, 1, 2]
+    assert Z.Y0 is None and Z.Y0inv is None and Z.Y0p is None
+    assert Z.Y0_file_out == "/tmp/maps/Y0_ncol120_L50.nc"                       # sph_zonal_mean.py:169
+    assert Z.Y0p_file_out == "/tmp/maps/Y0p_ncol120_1.0deg_L50.nc"              # :173
+    w = np.full(120, 1 / 120)
+    Zw = sph_zonal_averager(lat, lat_out, 5, weights=w)
+    assert np.allclose(Zw.weights, 4 * np.pi / 120) and np.allclose(w, 1 / 120)  # scaled copy (:181)
+
+
+def test_shard_bounds():
+    from pytemdiags_amd.sharding import shard_bounds
+    b = [shard_bounds(730, 8, r) for r in range(8)]
+    assert b[0] == (0, 92) and b[-1][1] == 730 and sorted(e - s for s, e in b) == [91] * 6 + [92] * 2
+    assert all(b[i][1] == b[i + 1][0] for i in range(7))
+    assert [shard_bounds(777602, 8, r)[1] - shard_bounds(777602, 8, r)[0] for r in range(8)].count(97200) == 6
+    assert shard_bounds(5, 8, 7) == (5, 5)

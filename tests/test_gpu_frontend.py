@@ -1,0 +1,125 @@
+"""GPU tests of the drop-in front end (TEMDiagnostics / sph_zonal_averager) against the goldens
+the reference produced: values, dtypes, dims, input kinds and error behaviour."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, fieldnorm_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+RESULTS = ("vtem", "omegatem", "wtem", "psitem", "epfy", "epfz", "epdiv", "utendepfd", "utendvtem", "utendwtem")
+ZONAL = ("ub", "vb", "thetab", "wapb", "upvpb", "upwappb", "vptpb", "dub_dp", "dthetab_dp", "ubcoslat",
+         "dubcoslat_dlat", "psi", "psicoslat", "dpsicoslat_dlat", "dpsi_dp", "int_vbdp")
+NATIVE = ("up", "vp", "thetap", "wapp", "upvp", "upwapp", "vptp")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def labeled(g, k):
+    from pytemdiags_amd import LabeledArray
+    return LabeledArray(g[k], ("ncol", "plev", "time"), {"plev": g["plev"], "time": g["time"]}, name=k)
+
+
+def vals(x):
+    v = x.values if hasattr(x, "dims") else x
+    return v.cpu().numpy() if hasattr(v, "cpu") else np.asarray(v)
+
+
+@pytest.mark.parametrize("case", ["tem_ne4_30x1_f64", "tem_ne4_30x1_f32", "tem_ne4_30x1_desc"])
+def test_temdiagnostics_labeled_matches_reference(case):
+    from pytemdiags_amd import TEMDiagnostics, LabeledArray
+    g = load(case)
+    tol = 2e-5 if g["ua"].dtype == np.float32 else 1e-10
+    lat = LabeledArray(g["lat"], ("ncol",))
+    tem = TEMDiagnostics(labeled(g, "ua"), labeled(g, "va"), labeled(g, "ta"), labeled(g, "wap"), lat,
+                         debug_level=0)
+    assert (tem.NCOL, tem.NLEV, tem.NT, tem.ZM_N) == (866, 30, 1, 180)
+    np.testing.assert_array_equal(tem.lat, g["lat_zm"])
+    assert tem.plev[0] < tem.plev[-1]                     # always ascending (tem_diagnostics.py:372-382)
+    for n in RESULTS:
+        r = getattr(tem, n)()
+        assert isinstance(r, LabeledArray) and r.dims == ("lat", "plev", "time") and r.name == n
+        assert r.dtype == g["res_" + n].dtype, n
+        assert fieldnorm_err(r.values, g["res_" + n]) <= tol, n
+        np.testing.assert_array_equal(r.coords["lat"], g["lat_zm"])
+    for n in ZONAL:
+        z = getattr(tem, n)
+        assert z.dtype == g["zm_" + n].dtype, n
+        assert fieldnorm_err(z.values, g["zm_" + n]) <= tol, n
+    if "nat_up" in g.files:
+        for n in NATIVE:
+            e = getattr(tem, n)
+            assert e.dims == ("ncol", "plev", "time") and e.dtype == g["nat_" + n].dtype, n
+            assert fieldnorm_err(e.values, g["nat_" + n]) <= tol, n
+        th = tem.theta
+        assert th.dtype == np.float64 and fieldnorm_err(th.values, g["theta"]) <= 1e-12
+
+
+def test_raw_numpy_torch_and_transposed_inputs():
+    from pytemdiags_amd import TEMDiagnostics
+    g = load("tem_ne4_12x3_L20_dlat3")
+    kw = dict(L=int(g["L"]), zm_dlat=float(g["zm_dlat"]), debug_level=0)
+    # raw numpy
+    t1 = TEMDiagnostics(g["ua"], g["va"], g["ta"], g["wap"], g["lat"], plev=g["plev"], time=g["time"], **kw)
+    r1 = t1.epdiv()
+    assert isinstance(r1, np.ndarray) and fieldnorm_err(r1, g["res_epdiv"]) <= 1e-10
+    # raw torch, (time, plev, ncol) order
+    tt = [torch.as_tensor(np.ascontiguousarray(np.transpose(g[k], (2, 1, 0))), device="cuda:0")
+          for k in ("ua", "va", "ta", "wap")]
+    t2 = TEMDiagnostics(*tt, g["lat"], plev=g["plev"], dims=("time", "plev", "ncol"), **kw)
+    r2 = t2.psitem()
+    assert isinstance(r2, torch.Tensor) and r2.is_cuda
+    assert fieldnorm_err(r2.cpu().numpy(), g["res_psitem"]) <= 1e-10
+    assert fieldnorm_err(t2.ub.cpu().numpy(), g["zm_ub"]) <= 1e-10
+
+
+def test_two_dimensional_input_is_accepted():
+    """The reference's 2-D path is broken; here (ncol, plev) works as one snapshot."""
+    from pytemdiags_amd import TEMDiagnostics
+    g = load("tem_ne4_30x1_f64")
+    f = [g[k][:, :, 0] for k in ("ua", "va", "ta", "wap")]
+    tem = TEMDiagnostics(*f, g["lat"], plev=g["plev"], debug_level=0)
+    assert fieldnorm_err(tem.vtem(), g["res_vtem"]) <= 1e-10
+
+
+def test_operator_frontend_and_errors():
+    from pytemdiags_amd import sph_zonal_averager, LabeledArray
+    g = load("op_ne4_L30")
+    ZM = sph_zonal_averager(g["lat"], g["lat_out"], int(g["L"]))
+    assert ZM.Y0 is None and ZM.Y0p is None and ZM.N == 866 and ZM.M == 90
+    assert ZM.grid_name == "ncol866" and ZM.grid_out_name == "2.0deg"
+    A = LabeledArray(g["in_rand3d"], ("ncol", "a", "b"), name="x")
+    with pytest.raises(RuntimeError):
+        ZM.sph_zonal_mean(A)                               # matrices undefined (sph_zonal_mean.py:213)
+    ZM.sph_compute_matrices()
+    assert np.max(np.abs(ZM.Y0 - g["Y0"])) < 2e-12 and np.max(np.abs(ZM.Y0p - g["Y0p"])) < 2e-12
+    assert np.max(np.abs(ZM.Y0inv @ ZM.Y0 - np.eye(31))) < 1e-12
+    d, o = ZM.sanity_check()
+    assert abs(d - 31) < 1e-10 and abs(o) < 1e-10
+    zm = ZM.sph_zonal_mean(A)
+    assert zm.dims == ("lat", "a", "b") and zm.attrs["long_name"] == "zonal mean of x"
+    assert np.max(np.abs(zm.values - g["zm_rand3d"])) < 1e-10
+    zn = ZM.sph_zonal_mean_native(A)
+    assert zn.dims == ("ncol", "a", "b") and np.max(np.abs(zn.values - g["zmn_rand3d"])) < 1e-10
+    a32 = ZM.sph_zonal_mean(g["in_rand3d_f32"])            # raw ndarray in -> ndarray out, input dtype
+    assert a32.dtype == np.float32 and np.max(np.abs(a32 - g["zm_rand3d_f32"])) < 1e-5
+    bad = g["in_y20"].copy(); bad[5] = np.nan
+    with pytest.raises(RuntimeError, match="nans"):
+        ZM.sph_zonal_mean(bad)
+    with pytest.raises(RuntimeError, match="leftmost"):
+        ZM.sph_zonal_mean(LabeledArray(g["in_rand3d"].transpose(1, 0, 2).copy(), ("a", "ncol", "b")))
+    with pytest.raises(RuntimeError, match="leftmost"):
+        ZM.sph_zonal_mean(np.zeros(17))
+
+
+def test_tem_nan_input_raises():
+    from pytemdiags_amd import TEMDiagnostics
+    g = load("tem_ne4_12x3_L20_dlat3")
+    ta = g["ta"].copy(); ta[100, 2, 1] = np.nan
+    with pytest.raises(RuntimeError, match="nans"):
+        TEMDiagnostics(g["ua"], g["va"], ta, g["wap"], g["lat"], plev=g["plev"], L=20, zm_dlat=3, debug_level=0)

@@ -1,0 +1,137 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU driver in pytemdiags_amd/sharding.py.
+
+The driver only sequences stages and collectives; here its backend is a CPU stand-in with the
+engine.Plan stage interface built on the oracle, so the test checks that ncol-sharded partial
+sums + all-reduce + redundant solve reproduce the single-process result, and that time sharding
++ ragged gather reassemble the time axis."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle import tem_oracle as orc          # noqa: E402
+from pytemdiags_amd import sharding, synth    # noqa: E402
+
+NE, NLEV, NT, L = 4, 6, 5, 12
+
+
+class OracleBackend:
+    """engine.Plan's stage interface on CPU tensors (test stand-in only)."""
+
+    def __init__(self, lat_local, lat_out, L, plev):
+        self.Y0 = orc.ylm0_matrix(lat_local, L)
+        self.Y0p = orc.ylm0_matrix(lat_out, L)
+        self.plev = np.asarray(plev)
+        self.scale = (orc.P0 / (self.plev * 100)) ** orc.k
+        self.Ginv = None
+
+    def matrix(self, which):
+        assert which == sharding.MAT_GRAM
+        return torch.from_numpy(self.Y0.T @ self.Y0)
+
+    def finalize(self, G):
+        self.Ginv = np.linalg.inv(G)
+
+    def _f(self, ua, va, ta, wap):
+        th = orc.multiply_p(ta, self.scale)
+        return [np.asarray(x).reshape(x.shape[0], -1) for x in (ua, va, th, wap)], ua.shape[1:]
+
+    def tem_stage1(self, ua, va, ta, wap):
+        X, _ = self._f(ua, va, ta, wap)
+        return torch.from_numpy(np.stack([self.Y0.T @ x for x in X]))
+
+    def tem_stage2(self, ua, va, ta, wap, B4):
+        X, tr = self._f(ua, va, ta, wap)
+        C = [self.Ginv @ b for b in B4.numpy()]
+        self.zon = {n: (self.Y0p @ c).reshape((-1,) + tr) for n, c in zip(("ub", "vb", "thetab", "wapb"), C)}
+        e = [x - self.Y0 @ c for x, c in zip(X, C)]
+        prods = [e[0] * e[1], e[0] * e[3], e[1] * e[2]]
+        self.tr = tr
+        return torch.from_numpy(np.stack([self.Y0.T @ p for p in prods]))
+
+    def tem_stage3(self, B3, want_zonal=False):
+        for n, b in zip(("upvpb", "upwappb", "vptpb"), B3.numpy()):
+            self.zon[n] = (self.Y0p @ (self.Ginv @ b)).reshape((-1,) + self.tr)
+        o = orc.TEMOracle.from_zonal_means(self.zon, self.plev)
+        res = torch.from_numpy(np.stack([getattr(o, n)() for n in orc.RESULTS]))
+        return res, None
+
+    def tem_run(self, ua, va, ta, wap, want_zonal=False):
+        B4 = self.tem_stage1(ua, va, ta, wap)
+        return self.tem_stage3(self.tem_stage2(ua, va, ta, wap, B4), want_zonal)
+
+
+def _data():
+    lat, lon = synth.cubed_sphere_gll(NE)
+    plev = synth.pressure_levels(NLEV)
+    f = synth.analytic_fields(lat, lon, plev, NT, seed=3)
+    return lat, plev, f
+
+
+def _worker(rank, world, port, mode, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lat, plev, f = _data()
+        lat_zm = orc.zm_latitudes(1)
+        if mode == "ncol":
+            i0, i1 = sharding.shard_bounds(lat.size, world, rank)
+            be = OracleBackend(lat[i0:i1], lat_zm, L, plev)
+            runner = sharding.NcolShardedTEM(be)
+            res, _ = runner.run(*[x[i0:i1] for x in f])
+        else:
+            be = OracleBackend(lat, lat_zm, L, plev)
+            be.finalize((be.Y0.T @ be.Y0))
+            runner = sharding.TimeShardedTEM(be, NT)
+            t0, t1 = runner.t0, runner.t1
+            res, _ = runner.run(*[np.ascontiguousarray(x[:, :, t0:t1]) for x in f])
+            res = sharding.gather_time(res)
+        if rank == 0:
+            ret.put(res.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("mode", ["ncol", "time"])
+def test_sharded_pipeline_world2_gloo(mode):
+    lat, plev, f = _data()
+    ref = orc.TEMOracle(*f, lat, plev, L=L, mode="factorised")
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = ret.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got.shape == (10, 180, NLEV, NT)
+    for i, n in enumerate(orc.RESULTS):
+        r = getattr(ref, n)()
+        err = np.max(np.abs(got[i] - r)) / np.max(np.abs(r))
+        assert err <= 1e-10, (mode, n, err)
+
+
+def test_world1_is_a_no_op():
+    t = torch.ones(3)
+    assert sharding.allreduce_sum_(t) is t and float(t.sum()) == 3.0
+    assert sharding.gather_time(t) is t
