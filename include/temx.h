@@ -111,9 +111,8 @@ int temx_project(temx_plan* plan, const void* A, int dtype, int64_t D, double* B
 int temx_zonal_mean(temx_plan* plan, const void* A, int dtype, int64_t D, double* out,
                     int native, void* stream);
 
-/* Second half of temx_zonal_mean for ncol-sharded use: B (all-reduced raw sums) -> out. A is
- * only read when native != 0 is requested... it is not: pass the rank's plan; out [M][D] or
- * this rank's [ncol][D]. */
+/* Second half of temx_zonal_mean, for ncol-sharded use: B[K][D] (raw sums, all-reduced over the
+ * ranks) -> out, [M][D] (native == 0) or this rank's own [ncol][D] block (native != 0). */
 int temx_zonal_mean_from_sums(temx_plan* plan, const double* B, int64_t D, double* out,
                               int native, void* stream);
 
