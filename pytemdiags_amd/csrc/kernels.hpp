@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #define TEMX_MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
 
 namespace temx {
@@ -141,9 +143,10 @@ project_kernel(FieldPtrs<NF> fp, int64_t N, int64_t D, int K, const double* __re
   constexpr int YJ = (YE + 255) / 256;       // staging loads per thread
   T xn[NF][4];
   double ys[YJ];
-  auto load_x = [&](int chunk, int ti) {
+  const int nfull = (int)(N >> 4);           // chunks whose 16 rows all exist
+  auto load_x = [&](int chunk, int ti, auto fastc) __attribute__((always_inline)) {
     const int64_t gb = (int64_t)chunk * 16 + ti * 4;   // first row of the group (uniform)
-    if (gb + 4 <= N) {
+    if (decltype(fastc)::value) {
 #pragma unroll
       for (int f = 0; f < NF; ++f) xn[f][ti] = (reinterpret_cast<const T*>(fp.p[f]) + gb * D)[loff];
     } else {                                  // ragged tail of the grid: clamp per lane
@@ -153,25 +156,19 @@ project_kernel(FieldPtrs<NF> fp, int64_t N, int64_t D, int K, const double* __re
       for (int f = 0; f < NF; ++f) xn[f][ti] = reinterpret_cast<const T*>(fp.p[f])[row * D + dcl];
     }
   };
-  auto load_ys = [&](int chunk) {             // yblk is padded: tid + 256 j never leaves it
+  auto load_ys = [&](int chunk) __attribute__((always_inline)) {   // yblk is padded: never leaves it
 #pragma unroll
     for (int j = 0; j < YJ; ++j) ys[j] = (yblk + (int64_t)chunk * YE)[tid + 256 * j];
   };
-
-  if (c0 < c1) {
-    load_ys(c0);
-    if (active) {
-#pragma unroll
-      for (int ti = 0; ti < 4; ++ti) load_x(c0, ti);
-    }
-  }
-  for (int chunk = c0; chunk < c1; ++chunk) {
+  // one chunk: stage Y0 blocks, barrier, prefetch chunk+1, 4 groups x TB x NF MFMAs
+  auto do_chunk = [&](int chunk, auto fastc) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(fastc)::value;     // FAST: chunk+1 < c1 and all its rows exist
     double* yst = ystage[(chunk - c0) & 1];
 #pragma unroll
     for (int j = 0; j < YJ; ++j)
       if (tid + 256 * j < YE) yst[tid + 256 * j] = ys[j];
     __syncthreads();
-    const bool more = chunk + 1 < c1;
+    const bool more = FAST || chunk + 1 < c1;
     if (more) load_ys(chunk + 1);
     if (active) {
 #pragma unroll
@@ -179,7 +176,7 @@ project_kernel(FieldPtrs<NF> fp, int64_t N, int64_t D, int K, const double* __re
         double xs[NF];
 #pragma unroll
         for (int f = 0; f < NF; ++f) xs[f] = (double)xn[f][ti] * sc[f];
-        if (more) load_x(chunk + 1, ti);
+        if (more) load_x(chunk + 1, ti, fastc);
 #pragma unroll
         for (int t = 0; t < TB; ++t) {
           const double ya = yst[(ti * TB + t) * 16 + yoff];
@@ -188,7 +185,19 @@ project_kernel(FieldPtrs<NF> fp, int64_t N, int64_t D, int K, const double* __re
         }
       }
     }
+  };
+
+  if (c0 < c1) {
+    load_ys(c0);
+    if (active) {
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) load_x(c0, ti, std::false_type{});
+    }
   }
+  const int cfast = (c1 < nfull ? c1 : nfull) - 1;   // chunks < cfast prefetch a complete chunk
+  int chunk = c0;
+  for (; chunk < cfast; ++chunk) do_chunk(chunk, std::true_type{});
+  for (; chunk < c1; ++chunk) do_chunk(chunk, std::false_type{});
 
   if (dvalid) {
 #pragma unroll
@@ -329,11 +338,12 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
 
   T xn[4][GR];
   double ys[YJ];
-  auto load_x = [&](int step) {
+  const int nfull = (int)(N / (4 * GR));     // steps whose rows all exist
+  auto load_x = [&](int step, auto fastc) __attribute__((always_inline)) {
 #pragma unroll
     for (int ti = 0; ti < GR; ++ti) {
       const int64_t gb = ((int64_t)step * GR + ti) * 4;
-      if (gb + 4 <= N) {
+      if (decltype(fastc)::value) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) xn[f][ti] = (reinterpret_cast<const T*>(fp.p[f]) + gb * D)[loff];
       } else {
@@ -344,19 +354,17 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
       }
     }
   };
-  auto load_ys = [&](int step) {              // the blocked arrays are padded by one chunk
+  auto load_ys = [&](int step) __attribute__((always_inline)) {   // the blocked array is padded by one chunk
 #pragma unroll
     for (int j = 0; j < YJ; ++j) ys[j] = (yblk + (int64_t)step * YE)[tid + 256 * j];
   };
 
-  if (c0 < c1) {
-    load_ys(c0);
-    if (active) load_x(c0);
-  }
-  // both halves run the same number of barrier rounds (the second half may idle in the last one)
-  for (int it = 0; it < nmax; ++it) {
+  // one barrier round.  FAST: this step and the next both exist for this half and the next one's
+  // rows are all inside the grid (no per-lane clamping, no liveness tests).
+  auto do_step = [&](int it, auto fastc) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(fastc)::value;
     const int step = c0 + it;
-    const bool live = step < c1;
+    const bool live = FAST || step < c1;
     double* yst = ystage + (it & 1) * YE;
     if (live) {
 #pragma unroll
@@ -364,10 +372,10 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
         if (tid + 256 * j < YE) yst[tid + 256 * j] = ys[j];
     }
     __syncthreads();
-    if (!live) continue;
-    const bool more = step + 1 < c1;
+    if (!live) return;
+    const bool more = FAST || step + 1 < c1;
     if (more) load_ys(step + 1);
-    if (!active) continue;
+    if (!active) return;
 
     double xs[4][GR];
 #pragma unroll
@@ -376,7 +384,7 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
       for (int ti = 0; ti < GR; ++ti) xs[f][ti] = (double)xn[f][ti];
 #pragma unroll
     for (int ti = 0; ti < GR; ++ti) xs[2][ti] *= sth;
-    if (more) load_x(step + 1);
+    if (more) load_x(step + 1, fastc);
 
     // The slab is loop invariant: without this, hipcc hoists all 4*TB LDS reads out of the loop
     // into 8*TB registers and spills.  Laundering the index keeps them as in-loop ds_reads.
@@ -435,7 +443,18 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
 #pragma unroll
         for (int q = 0; q < 3; ++q) acc[q][t] = TEMX_MFMA4(ya, p[q][ti], acc[q][t]);
       }
+  };
+
+  if (c0 < c1) {
+    load_ys(c0);
+    if (active) load_x(c0, std::false_type{});
   }
+  // both halves run the same number of barrier rounds (the second half may idle in the last one)
+  int nfast = (c1 < nfull ? c1 : nfull) - 1 - c0;
+  nfast = nfast < 0 ? 0 : (nfast > nmax ? nmax : nfast);
+  int it = 0;
+  for (; it < nfast; ++it) do_step(it, std::true_type{});
+  for (; it < nmax; ++it) do_step(it, std::false_type{});
 
   if (dvalid && partial != nullptr) {
     const int64_t slab = (int64_t)split * 2 + half;
