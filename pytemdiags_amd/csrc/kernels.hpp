@@ -105,22 +105,27 @@ __device__ __forceinline__ bool wg_work(int ndq, int nsplit, int& split, int& dq
 // no LDS, no barriers.  X is read exactly once from HBM, re-loaded one chunk ahead into the
 // registers it has just been consumed from; Y0 blocks (L2) run TB operands ahead in a ring.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NF, int TB>
-__global__ void __launch_bounds__(256, 2)
+template <typename T, int NF, int NFW, int TB, int PD, int WPS>
+__global__ void __launch_bounds__(256, WPS)
 project_kernel(FieldPtrs<NF> fp, int64_t N, int64_t D, int K, const double* __restrict__ yblk,
                int64_t nchunk, const double* __restrict__ colscale, int sfield,
                double* __restrict__ partial, int nsplit, int ndt) {
+  // NFW fields per wave: a workgroup's 4 waves cover DPW = 4*NFW/NF d-tiles x NF/NFW field groups.
+  // Fewer fields per wave = fewer accumulator registers = room for a deeper X ring and a third
+  // wave per SIMD (more independent instruction streams to overlap HBM latency with MFMA issue).
+  constexpr int DPW = 4 * NFW / NF;
   // Y0 blocks of one chunk (4 groups x TB blocks x 16), double buffered.  They come through LDS
   // rather than straight into registers because vector loads retire in order: an operand load
   // issued every few MFMAs would make every wait also wait for the youngest HBM loads of X.
   __shared__ double ystage[2][4 * TB * 16];
   int split, dq;
-  if (!wg_work((ndt + 3) >> 2, nsplit, split, dq)) return;
+  if (!wg_work((ndt + DPW - 1) / DPW, nsplit, split, dq)) return;
   const int wave = uniform_wave();
   const int tid = threadIdx.x, lane = tid & 63;
   const int c = lane & 15, g = lane >> 4;
-  const int dt = dq * 4 + wave;
-  const bool active = dt < ndt;                        // ragged last quad: helper waves only stage
+  const int dt = dq * DPW + wave % DPW;
+  const int f0 = (wave / DPW) * NFW;                   // first field of this wave
+  const bool active = dt < ndt;                        // ragged last workgroup: helper waves only stage
   const int64_t d = (int64_t)dt * 16 + c;
   const bool dvalid = active && d < D;
   const int64_t dcl = d < D ? d : D - 1;
@@ -129,83 +134,111 @@ project_kernel(FieldPtrs<NF> fp, int64_t N, int64_t D, int K, const double* __re
   // addressing: wave-uniform base (SGPR) + one 32-bit lane offset
   const uint32_t loff = (uint32_t)(g * D + dcl);          // host guarantees 4*D < 2^31
   const uint32_t yoff = (uint32_t)(g * 4 + (lane & 3));   // A[i = lane&3 -> l][k = lane>>4 -> row]
-  double sc[NF];
+  double sc[NFW];
+  const T* fb[NFW];
 #pragma unroll
-  for (int f = 0; f < NF; ++f) sc[f] = (colscale != nullptr && f == sfield) ? colscale[dcl] : 1.0;
+  for (int f = 0; f < NFW; ++f) {
+    sc[f] = (colscale != nullptr && f0 + f == sfield) ? colscale[dcl] : 1.0;
+    fb[f] = reinterpret_cast<const T*>(fp.p[f0 + f]);
+  }
 
-  double acc[NF][TB];
+  double acc[NFW][TB];
 #pragma unroll
-  for (int f = 0; f < NF; ++f)
+  for (int f = 0; f < NFW; ++f)
 #pragma unroll
     for (int t = 0; t < TB; ++t) acc[f][t] = 0.0;
 
   constexpr int YE = 4 * TB * 16;            // doubles of Y0 blocks per chunk
   constexpr int YJ = (YE + 255) / 256;       // staging loads per thread
-  T xn[NF][4];
+  // X runs PD chunks ahead in a register ring (HBM latency under load is longer than the MFMA
+  // time of one chunk); the chunk loop is unrolled by PD so ring slots are compile-time.
+  T xn[PD][NFW][4];
   double ys[YJ];
   const int nfull = (int)(N >> 4);           // chunks whose 16 rows all exist
-  auto load_x = [&](int chunk, int ti, auto fastc) __attribute__((always_inline)) {
+  auto load_x = [&](int chunk, auto slotc, int ti, auto fastc) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slotc)::value;
     const int64_t gb = (int64_t)chunk * 16 + ti * 4;   // first row of the group (uniform)
     if (decltype(fastc)::value) {
 #pragma unroll
-      for (int f = 0; f < NF; ++f) xn[f][ti] = (reinterpret_cast<const T*>(fp.p[f]) + gb * D)[loff];
+      for (int f = 0; f < NFW; ++f) xn[slot][f][ti] = (fb[f] + gb * D)[loff];
     } else {                                  // ragged tail of the grid: clamp per lane
       int64_t row = gb + g;
       row = row < N ? row : N - 1;
 #pragma unroll
-      for (int f = 0; f < NF; ++f) xn[f][ti] = reinterpret_cast<const T*>(fp.p[f])[row * D + dcl];
+      for (int f = 0; f < NFW; ++f) xn[slot][f][ti] = fb[f][row * D + dcl];
     }
   };
   auto load_ys = [&](int chunk) __attribute__((always_inline)) {   // yblk is padded: never leaves it
 #pragma unroll
     for (int j = 0; j < YJ; ++j) ys[j] = (yblk + (int64_t)chunk * YE)[tid + 256 * j];
   };
-  // one chunk: stage Y0 blocks, barrier, prefetch chunk+1, 4 groups x TB x NF MFMAs
-  auto do_chunk = [&](int chunk, auto fastc) __attribute__((always_inline)) {
-    constexpr bool FAST = decltype(fastc)::value;     // FAST: chunk+1 < c1 and all its rows exist
+  // one chunk: stage Y0 blocks, barrier, prefetch Y of chunk+1 and X of chunk+PD,
+  // 4 groups x TB x NFW MFMAs
+  auto do_chunk = [&](int chunk, auto slotc, auto fastc) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(fastc)::value;     // FAST: chunk+PD < c1 and all its rows exist
+    constexpr int slot = decltype(slotc)::value;
     double* yst = ystage[(chunk - c0) & 1];
 #pragma unroll
     for (int j = 0; j < YJ; ++j)
       if (tid + 256 * j < YE) yst[tid + 256 * j] = ys[j];
     __syncthreads();
-    const bool more = FAST || chunk + 1 < c1;
-    if (more) load_ys(chunk + 1);
+    if (FAST || chunk + 1 < c1) load_ys(chunk + 1);
+    const bool more = FAST || chunk + PD < c1;
     if (active) {
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti) {
-        double xs[NF];
+        double xs[NFW];
 #pragma unroll
-        for (int f = 0; f < NF; ++f) xs[f] = (double)xn[f][ti] * sc[f];
-        if (more) load_x(chunk + 1, ti, fastc);
+        for (int f = 0; f < NFW; ++f) xs[f] = (double)xn[slot][f][ti] * sc[f];
+        if (more) load_x(chunk + PD, slotc, ti, fastc);
 #pragma unroll
         for (int t = 0; t < TB; ++t) {
           const double ya = yst[(ti * TB + t) * 16 + yoff];
 #pragma unroll
-          for (int f = 0; f < NF; ++f) acc[f][t] = TEMX_MFMA4(ya, xs[f], acc[f][t]);
+          for (int f = 0; f < NFW; ++f) acc[f][t] = TEMX_MFMA4(ya, xs[f], acc[f][t]);
         }
       }
     }
+  };
+  // PD consecutive chunks, ring slot = position in the unrolled group
+  auto do_group = [&](int chunk, auto fastc) __attribute__((always_inline)) {
+    do_chunk(chunk, std::integral_constant<int, 0>{}, fastc);
+    if (PD > 1 && (decltype(fastc)::value || chunk + 1 < c1))
+      do_chunk(chunk + 1, std::integral_constant<int, (PD > 1 ? 1 : 0)>{}, fastc);
+    if (PD > 2 && (decltype(fastc)::value || chunk + 2 < c1))
+      do_chunk(chunk + 2, std::integral_constant<int, (PD > 2 ? 2 : 0)>{}, fastc);
   };
 
   if (c0 < c1) {
     load_ys(c0);
     if (active) {
 #pragma unroll
-      for (int ti = 0; ti < 4; ++ti) load_x(c0, ti, std::false_type{});
+      for (int ti = 0; ti < 4; ++ti) load_x(c0, std::integral_constant<int, 0>{}, ti, std::false_type{});
+      if (PD > 1 && c0 + 1 < c1) {
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+          load_x(c0 + 1, std::integral_constant<int, (PD > 1 ? 1 : 0)>{}, ti, std::false_type{});
+      }
+      if (PD > 2 && c0 + 2 < c1) {
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+          load_x(c0 + 2, std::integral_constant<int, (PD > 2 ? 2 : 0)>{}, ti, std::false_type{});
+      }
     }
   }
-  const int cfast = (c1 < nfull ? c1 : nfull) - 1;   // chunks < cfast prefetch a complete chunk
+  // chunks c with c + 2*PD - 1 < min(c1, nfull) run whole groups on the clamp-free path
+  const int cfast = (c1 < nfull ? c1 : nfull) - (2 * PD - 1);
   int chunk = c0;
-  for (; chunk < cfast; ++chunk) do_chunk(chunk, std::true_type{});
-  for (; chunk < c1; ++chunk) do_chunk(chunk, std::false_type{});
+  for (; chunk < cfast; chunk += PD) do_group(chunk, std::true_type{});
+  for (; chunk < c1; chunk += PD) do_group(chunk, std::false_type{});
 
   if (dvalid) {
 #pragma unroll
-    for (int f = 0; f < NF; ++f)
+    for (int f = 0; f < NFW; ++f)
 #pragma unroll
       for (int t = 0; t < TB; ++t) {
         const int l = t * 4 + g;
-        if (l < K) partial[(((int64_t)split * NF + f) * K + l) * D + d] = acc[f][t];
+        if (l < K) partial[(((int64_t)split * NF + f0 + f) * K + l) * D + d] = acc[f][t];
       }
   }
 }
@@ -289,19 +322,21 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
             int64_t nchunk, const double* __restrict__ colscale,
             const double* __restrict__ C, double* __restrict__ partial, int nsplit, int ndt,
             EddyOut eo) {
-  // LDS: [4 d-tiles][4 fields][TB][64] coefficient slabs, then per half, double buffered, the Y0
-  // blocks of one step (GR x TB x 16), read by the reconstruction as A[column][harmonic] and by
-  // the projection as A[harmonic][column].  (TEMDiagnostics never uses the weights mode of the
-  // averager, tem_diagnostics.py:243-246, so one unscaled copy serves both.)
+  // LDS: [4 d-tiles][4 fields][TB][64] coefficient slabs, then one private copy per wave of the
+  // Y0 blocks of the current step (GR x TB x 16), read by the reconstruction as
+  // A[column][harmonic] and by the projection as A[harmonic][column].  Wave-private staging
+  // (each wave re-reads the blocks from L2) keeps the kernel free of barriers: with one
+  // 8-wave workgroup per CU a per-step barrier stalled both waves of every SIMD at once
+  // (measured 22.3 -> 19.8 ms on ne120x72x30).  LDS operations of one wave execute in order, so
+  // a single buffer is enough: the next step's blocks are written after this step's reads.
   extern __shared__ double lds[];
   constexpr int GR = EDDY_GR;
   constexpr int YE = GR * TB * 16;           // doubles of Y0 blocks per step
-  constexpr int YJ = (YE + 255) / 256;       // staging loads per thread (256 threads per half)
+  constexpr int YJ = (YE + 63) / 64;         // staging loads per lane
   int split, dq;
   if (!wg_work((ndt + 3) >> 2, nsplit, split, dq)) return;
   const int wave = uniform_wave(), lane = threadIdx.x & 63;
   const int w4 = wave & 3, half = wave >> 2;
-  const int tid = threadIdx.x & 255;         // thread index inside the half
   const int c = lane & 15, g = lane >> 4;
   const int dt = dq * 4 + w4;
   const bool active = dt < ndt;
@@ -312,7 +347,6 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
   const int s0 = (int)(nstep * split / nsplit), s1 = (int)(nstep * (split + 1) / nsplit);
   const int sm = s0 + (s1 - s0 + 1) / 2;
   const int c0 = half ? sm : s0, c1 = half ? s1 : sm;   // uniform (SGPR)
-  const int nmax = sm - s0;                              // first half is never the shorter one
 
   // coefficient B operands: cb[f][s][lane] = C_f[4 s + g][d]; both halves write identical values
   {
@@ -323,7 +357,7 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
       for (int s = 0; s < TB; ++s) cb[(f * TB + s) * 64] = C[((int64_t)f * 4 * TB + 4 * s + g) * D + dcl];
   }
   int cbi = w4 * (4 * TB * 64) + lane;   // index of this lane's first slab element in lds[]
-  double* ystage = lds + 4 * 4 * TB * 64 + half * (2 * YE);   // [buf][YE]
+  double* yst = lds + 4 * 4 * TB * 64 + wave * YE;   // this wave's copy of the step's Y0 blocks
 
   const double sth = colscale != nullptr ? colscale[dcl] : 1.0;
   const uint32_t loff = (uint32_t)(g * D + dcl);
@@ -356,26 +390,18 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
   };
   auto load_ys = [&](int step) __attribute__((always_inline)) {   // the blocked array is padded by one chunk
 #pragma unroll
-    for (int j = 0; j < YJ; ++j) ys[j] = (yblk + (int64_t)step * YE)[tid + 256 * j];
+    for (int j = 0; j < YJ; ++j) ys[j] = (yblk + (int64_t)step * YE)[lane + 64 * j];
   };
 
-  // one barrier round.  FAST: this step and the next both exist for this half and the next one's
-  // rows are all inside the grid (no per-lane clamping, no liveness tests).
-  auto do_step = [&](int it, auto fastc) __attribute__((always_inline)) {
+  // one step.  FAST: the next step exists for this wave and its rows are all inside the grid
+  // (no per-lane clamping, no liveness tests).
+  auto do_step = [&](int step, auto fastc) __attribute__((always_inline)) {
     constexpr bool FAST = decltype(fastc)::value;
-    const int step = c0 + it;
-    const bool live = FAST || step < c1;
-    double* yst = ystage + (it & 1) * YE;
-    if (live) {
 #pragma unroll
-      for (int j = 0; j < YJ; ++j)
-        if (tid + 256 * j < YE) yst[tid + 256 * j] = ys[j];
-    }
-    __syncthreads();
-    if (!live) return;
+    for (int j = 0; j < YJ; ++j)
+      if (lane + 64 * j < YE) yst[lane + 64 * j] = ys[j];
     const bool more = FAST || step + 1 < c1;
     if (more) load_ys(step + 1);
-    if (!active) return;
 
     double xs[4][GR];
 #pragma unroll
@@ -445,16 +471,15 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
       }
   };
 
+  if (!active) return;                      // ragged last quad: nothing to do, nobody waits
   if (c0 < c1) {
     load_ys(c0);
-    if (active) load_x(c0, std::false_type{});
+    load_x(c0, std::false_type{});
   }
-  // both halves run the same number of barrier rounds (the second half may idle in the last one)
-  int nfast = (c1 < nfull ? c1 : nfull) - 1 - c0;
-  nfast = nfast < 0 ? 0 : (nfast > nmax ? nmax : nfast);
-  int it = 0;
-  for (; it < nfast; ++it) do_step(it, std::true_type{});
-  for (; it < nmax; ++it) do_step(it, std::false_type{});
+  const int cfast = (c1 < nfull ? c1 : nfull) - 1;
+  int step = c0;
+  for (; step < cfast; ++step) do_step(step, std::true_type{});
+  for (; step < c1; ++step) do_step(step, std::false_type{});
 
   if (dvalid && partial != nullptr) {
     const int64_t slab = (int64_t)split * 2 + half;

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -67,7 +68,7 @@ struct DevBuf {
 };
 
 struct Split {
-  int ndt = 0, nsplit = 0, grid = 0;
+  int ndt = 0, nsplit = 0, grid = 0, dpw = 4;   // dpw: d-tiles per workgroup
 };
 
 struct TimedLaunch {
@@ -109,10 +110,11 @@ static int upload(DevBuf& b, const void* src, size_t bytes) {
 // How to cut (d-tiles x chunk range) into wave-sized work so that `slots` workgroup slots
 // (CUs x resident workgroups) are evenly filled.  Smaller nsplit is preferred on near-ties
 // (fewer partial slabs to write and re-read).
-static Split choose_split(int64_t D, int64_t nchunk, int slots) {
+static Split choose_split(int64_t D, int64_t nchunk, int slots, int dpw = 4) {
   Split s;
+  s.dpw = dpw;
   s.ndt = (int)((D + 15) / 16);
-  const int ndq = (s.ndt + 3) / 4;            // a workgroup owns 4 consecutive d-tiles
+  const int ndq = (s.ndt + dpw - 1) / dpw;    // a workgroup owns dpw consecutive d-tiles
   int64_t maxsplit = std::max<int64_t>(1, nchunk / 4);
   maxsplit = std::min<int64_t>(maxsplit, std::max<int64_t>(1, (int64_t)4 * slots / ndq + 1));
   maxsplit = std::min<int64_t>(maxsplit, 4096);
@@ -149,13 +151,40 @@ static void time_end(temx_plan* pl, int which, hipStream_t st, TimedLaunch& tl) 
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NF>
-static int launch_project_t(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t D, const double* colscale,
+// sweep-1 configuration: fields per wave, X ring depth, waves per SIMD
+struct ProjCfgA { static constexpr int NFW = 2, PD = 2, WPS = 3; };
+struct ProjCfgB { static constexpr int NFW = 2, PD = 3, WPS = 2; };
+struct ProjCfgC { static constexpr int NFW = 4, PD = 1, WPS = 2; };
+struct ProjCfgD { static constexpr int NFW = 2, PD = 1, WPS = 3; };
+struct ProjCfg1 { static constexpr int NFW = 1, PD = 2, WPS = 2; };
+static int proj_cfg_id() {
+  static int id = -1;
+  if (id < 0) {
+    const char* e = getenv("TEMX_PROJ_CFG");
+    id = e ? (e[0] - 'A') : 2;   // default C: 4 fields per wave, measured best by a hair
+    if (id < 0 || id > 3) id = 0;
+  }
+  return id;
+}
+static int proj_dpw(int NF) {
+  if (NF == 1) return 4;
+  const int nfw[4] = {ProjCfgA::NFW, ProjCfgB::NFW, ProjCfgC::NFW, ProjCfgD::NFW};
+  return 4 * nfw[proj_cfg_id()] / 4;
+}
+static int proj_wps(int NF) {
+  if (NF == 1) return 2;
+  const int w[4] = {ProjCfgA::WPS, ProjCfgB::WPS, ProjCfgC::WPS, ProjCfgD::WPS};
+  return w[proj_cfg_id()];
+}
+
+template <typename T, int NF, typename Cfg>
+static int launch_project_c(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t D, const double* colscale,
                             int sfield, double* partial, const Split& sp, hipStream_t st) {
   dim3 grid(sp.grid), block(256);
-#define TEMX_LP(TBv)                                                                              \
-  hipLaunchKernelGGL((project_kernel<T, NF, TBv>), grid, block, 0, st, fp, pl->N, D, pl->K,       \
-                     pl->yproj_ptr(), pl->nchunk, colscale, sfield, partial, sp.nsplit, sp.ndt)
+#define TEMX_LP(TBv)                                                                                  \
+  hipLaunchKernelGGL((project_kernel<T, NF, Cfg::NFW, TBv, Cfg::PD, Cfg::WPS>), grid, block, 0, st, fp, \
+                     pl->N, D, pl->K, pl->yproj_ptr(), pl->nchunk, colscale, sfield, partial,         \
+                     sp.nsplit, sp.ndt)
   switch (pl->TB) {
     case 4: TEMX_LP(4); break;
     case 8: TEMX_LP(8); break;
@@ -165,6 +194,21 @@ static int launch_project_t(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t D, c
 #undef TEMX_LP
   HIPCHK(hipGetLastError());
   return TEMX_OK;
+}
+
+template <typename T, int NF>
+static int launch_project_t(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t D, const double* colscale,
+                            int sfield, double* partial, const Split& sp, hipStream_t st) {
+  if constexpr (NF == 1) {
+    return launch_project_c<T, NF, ProjCfg1>(pl, fp, D, colscale, sfield, partial, sp, st);
+  } else {
+    switch (proj_cfg_id()) {
+      case 1: return launch_project_c<T, NF, ProjCfgB>(pl, fp, D, colscale, sfield, partial, sp, st);
+      case 2: return launch_project_c<T, NF, ProjCfgC>(pl, fp, D, colscale, sfield, partial, sp, st);
+      case 3: return launch_project_c<T, NF, ProjCfgD>(pl, fp, D, colscale, sfield, partial, sp, st);
+      default: return launch_project_c<T, NF, ProjCfgA>(pl, fp, D, colscale, sfield, partial, sp, st);
+    }
+  }
 }
 
 template <int NF>
@@ -201,7 +245,7 @@ static int launch_eddy_t(temx_plan* pl, const FieldPtrs<4>& fp, double* partial,
 #define TEMX_LE(TBv)                                                                                  \
   do {                                                                                                \
     auto kern = eddy_kernel<T, TBv, MODE>;                                                            \
-    const size_t lds = ((size_t)4 * 4 * TBv * 64 + 2 * 2 * EDDY_GR * TBv * 16) * sizeof(double);      \
+    const size_t lds = ((size_t)4 * 4 * TBv * 64 + 8 * EDDY_GR * TBv * 16) * sizeof(double);          \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
     hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->N, pl->D, pl->K, pl->yblk.d(),             \
@@ -588,7 +632,7 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
   }
   if ((rc = upload(pl->colscale, cs.data(), cs.size() * 8))) return rc;
 
-  pl->sp_proj4 = choose_split(D, pl->nchunk, 2 * pl->num_cu);
+  pl->sp_proj4 = choose_split(D, pl->nchunk, proj_wps(4) * pl->num_cu, proj_dpw(4));
   // eddy sweep: one 8-wave workgroup per CU (LDS slab), each work id is shared by two waves that
   // halve its chunk range -> 2 partial slabs per split
   pl->sp_eddy = choose_split(D, pl->nchunk / 2, pl->num_cu);
