@@ -243,21 +243,36 @@ project_kernel(FieldPtrs<NF> fp, int64_t N, int64_t D, int K, const double* __re
   }
 }
 
-// fixed-order (deterministic) sum of the per-split slabs; flags non-finite sums (NaN inputs).
-__global__ void reduce_partials_kernel(const double* __restrict__ partial, int nsplit, int64_t n,
-                                       double* __restrict__ B, int* __restrict__ flag) {
-  int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (idx >= n) return;
+// Deterministic sum of the per-split slabs; flags non-finite sums (NaN inputs).
+// A block owns 16 consecutive entries; its 256 threads are 16 entries x 16 split lanes, so small
+// problems (few entries, hundreds of splits) still spread over hundreds of blocks.  Each split lane
+// sums its splits in ascending order, the 16 lane sums are combined in a fixed order.
+__global__ void __launch_bounds__(256)
+reduce_partials_kernel(const double* __restrict__ partial, int nsplit, int64_t n,
+                       double* __restrict__ B, int* __restrict__ flag) {
+  __shared__ double sh[16][17];
+  const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int64_t idx = (int64_t)blockIdx.x * 16 + e;
   double s = 0.0;
-  for (int sp = 0; sp < nsplit; ++sp) s += partial[(int64_t)sp * n + idx];
-  B[idx] = s;
-  if (!(fabs(s) <= 1.79769313486231570815e308)) atomicOr(flag, 1);
+  if (idx < n)
+    for (int sp = sl; sp < nsplit; sp += 16) s += partial[(int64_t)sp * n + idx];
+  sh[sl][e] = s;
+  __syncthreads();
+  if (sl == 0 && idx < n) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += sh[j][e];
+    B[idx] = t;
+    if (!(fabs(t) <= 1.79769313486231570815e308)) atomicOr(flag, 1);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
 // solve: C = Ginv . B (harmonic coefficients, pinv(Y0) A = G^-1 Y0^T A, replaces the lstsq of
 // sph_zonal_mean.py:389) and Xb = Y0p . C (the outer matmul with Y = Y0p of :251).
-// One block per (field, 16 columns).  C is stored with K4 = 4*S rows (rows >= K zero).
+// One block per (16 columns, field, slice of the M output latitudes); every slice recomputes the
+// K x 16 coefficients (cheap) so that small problems still fill the chip.  C is stored with
+// K4 = 4*TB rows (rows >= K zero) by slice 0.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 solve_kernel(const double* __restrict__ B, int K, int K4, int M, int64_t D,
@@ -283,12 +298,15 @@ solve_kernel(const double* __restrict__ B, int K, int K4, int M, int64_t D,
       for (int kk = 0; kk < K; ++kk) v += gr[kk] * sb[kk][dd];
     }
     scf[k][dd] = v;
-    if (C != nullptr && d < D) C[((int64_t)f * K4 + k) * D + d] = v;
+    if (C != nullptr && blockIdx.z == 0 && d < D) C[((int64_t)f * K4 + k) * D + d] = v;
   }
   __syncthreads();
   if (Xb != nullptr) {
-    for (int idx = tid; idx < M * 16; idx += 256) {
-      const int m = idx >> 4, dd = idx & 15;
+    const int mper = (M + gridDim.z - 1) / gridDim.z;
+    const int m0 = blockIdx.z * mper;
+    const int m1 = m0 + mper < M ? m0 + mper : M;
+    for (int idx = tid; idx < (m1 - m0) * 16; idx += 256) {
+      const int m = m0 + (idx >> 4), dd = idx & 15;
       const int64_t d = d0 + dd;
       if (d >= D) continue;
       const double* yr = Y0p + (int64_t)m * K;
@@ -316,13 +334,15 @@ solve_kernel(const double* __restrict__ B, int K, int K4, int M, int64_t D,
 // ------------------------------------------------------------------------------------------------
 constexpr int EDDY_GR = 2;   // groups (of 4 columns) per eddy step: 8 columns x 16 (lev,time)
 
-template <typename T, int TB, int MODE>
+template <typename T, int TB, int MODE, int DPW>
 __global__ void __launch_bounds__(512, 2)
 eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restrict__ yblk,
             int64_t nchunk, const double* __restrict__ colscale,
             const double* __restrict__ C, double* __restrict__ partial, int nsplit, int ndt,
             EddyOut eo) {
-  // LDS: [4 d-tiles][4 fields][TB][64] coefficient slabs, then one private copy per wave of the
+  // A workgroup (8 waves) owns DPW d-tiles (4, 2 or 1); the NP = 8/DPW waves on one d-tile share
+  // its coefficient slab and split the chunk range NP ways (small D: fewer, evenly loaded tiles).
+  // LDS: [DPW d-tiles][4 fields][TB][64] coefficient slabs, then one private copy per wave of the
   // Y0 blocks of the current step (GR x TB x 16), read by the reconstruction as
   // A[column][harmonic] and by the projection as A[harmonic][column].  Wave-private staging
   // (each wave re-reads the blocks from L2) keeps the kernel free of barriers: with one
@@ -333,22 +353,23 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
   constexpr int GR = EDDY_GR;
   constexpr int YE = GR * TB * 16;           // doubles of Y0 blocks per step
   constexpr int YJ = (YE + 63) / 64;         // staging loads per lane
+  constexpr int NP = 8 / DPW;
   int split, dq;
-  if (!wg_work((ndt + 3) >> 2, nsplit, split, dq)) return;
+  if (!wg_work((ndt + DPW - 1) / DPW, nsplit, split, dq)) return;
   const int wave = uniform_wave(), lane = threadIdx.x & 63;
-  const int w4 = wave & 3, half = wave >> 2;
+  const int w4 = wave % DPW, part = wave / DPW;
   const int c = lane & 15, g = lane >> 4;
-  const int dt = dq * 4 + w4;
+  const int dt = dq * DPW + w4;
   const bool active = dt < ndt;
   const int64_t d = (int64_t)dt * 16 + c;
   const bool dvalid = active && d < D;
   const int64_t dcl = d < D ? d : D - 1;
   const int64_t nstep = nchunk * (4 / GR);
-  const int s0 = (int)(nstep * split / nsplit), s1 = (int)(nstep * (split + 1) / nsplit);
-  const int sm = s0 + (s1 - s0 + 1) / 2;
-  const int c0 = half ? sm : s0, c1 = half ? s1 : sm;   // uniform (SGPR)
+  const int64_t sub = (int64_t)split * NP + part, nsub = (int64_t)nsplit * NP;
+  const int c0 = (int)(nstep * sub / nsub), c1 = (int)(nstep * (sub + 1) / nsub);   // uniform (SGPR)
 
-  // coefficient B operands: cb[f][s][lane] = C_f[4 s + g][d]; both halves write identical values
+  // coefficient B operands: cb[f][s][lane] = C_f[4 s + g][d]; all NP waves on the d-tile write
+  // identical values (no barrier needed)
   {
     double* cb = lds + (size_t)w4 * (4 * TB * 64) + lane;
 #pragma unroll
@@ -357,7 +378,7 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
       for (int s = 0; s < TB; ++s) cb[(f * TB + s) * 64] = C[((int64_t)f * 4 * TB + 4 * s + g) * D + dcl];
   }
   int cbi = w4 * (4 * TB * 64) + lane;   // index of this lane's first slab element in lds[]
-  double* yst = lds + 4 * 4 * TB * 64 + wave * YE;   // this wave's copy of the step's Y0 blocks
+  double* yst = lds + DPW * 4 * TB * 64 + wave * YE;   // this wave's copy of the step's Y0 blocks
 
   const double sth = colscale != nullptr ? colscale[dcl] : 1.0;
   const uint32_t loff = (uint32_t)(g * D + dcl);
@@ -482,7 +503,7 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
   for (; step < c1; ++step) do_step(step, std::false_type{});
 
   if (dvalid && partial != nullptr) {
-    const int64_t slab = (int64_t)split * 2 + half;
+    const int64_t slab = sub;
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll

@@ -156,6 +156,7 @@ struct ProjCfgA { static constexpr int NFW = 2, PD = 2, WPS = 3; };
 struct ProjCfgB { static constexpr int NFW = 2, PD = 3, WPS = 2; };
 struct ProjCfgC { static constexpr int NFW = 4, PD = 1, WPS = 2; };
 struct ProjCfgD { static constexpr int NFW = 2, PD = 1, WPS = 3; };
+struct ProjCfgE { static constexpr int NFW = 1, PD = 2, WPS = 3; };   // small D: one d-tile per workgroup
 struct ProjCfg1 { static constexpr int NFW = 1, PD = 2, WPS = 2; };
 static int proj_cfg_id() {
   static int id = -1;
@@ -166,13 +167,28 @@ static int proj_cfg_id() {
   }
   return id;
 }
-static int proj_dpw(int NF) {
+// d-tiles per workgroup that waste the fewest wave slots on a ragged last workgroup
+static int pick_dpw(int ndt, int maxdpw) {
+  int best = maxdpw;
+  double bw = 1e9;
+  for (int d = maxdpw; d >= 1; d >>= 1) {
+    const double w = (double)(((ndt + d - 1) / d) * d) / ndt;
+    if (w < bw - 0.05) {
+      bw = w;
+      best = d;
+    }
+  }
+  return best;
+}
+static int proj_dpw(int NF, int ndt) {
   if (NF == 1) return 4;
   const int nfw[4] = {ProjCfgA::NFW, ProjCfgB::NFW, ProjCfgC::NFW, ProjCfgD::NFW};
-  return 4 * nfw[proj_cfg_id()] / 4;
+  const int d = 4 * nfw[proj_cfg_id()] / 4;
+  return pick_dpw(ndt, d) == 1 ? 1 : d;     // small ragged D: config E (1 field per wave)
 }
-static int proj_wps(int NF) {
+static int proj_wps(int NF, int dpw) {
   if (NF == 1) return 2;
+  if (dpw == 1) return ProjCfgE::WPS;
   const int w[4] = {ProjCfgA::WPS, ProjCfgB::WPS, ProjCfgC::WPS, ProjCfgD::WPS};
   return w[proj_cfg_id()];
 }
@@ -202,6 +218,7 @@ static int launch_project_t(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t D, c
   if constexpr (NF == 1) {
     return launch_project_c<T, NF, ProjCfg1>(pl, fp, D, colscale, sfield, partial, sp, st);
   } else {
+    if (sp.dpw == 1) return launch_project_c<T, NF, ProjCfgE>(pl, fp, D, colscale, sfield, partial, sp, st);
     switch (proj_cfg_id()) {
       case 1: return launch_project_c<T, NF, ProjCfgB>(pl, fp, D, colscale, sfield, partial, sp, st);
       case 2: return launch_project_c<T, NF, ProjCfgC>(pl, fp, D, colscale, sfield, partial, sp, st);
@@ -222,7 +239,7 @@ static int launch_project(temx_plan* pl, const FieldPtrs<NF>& fp, int dtype, int
 
 static int launch_reduce(temx_plan* pl, const double* partial, int nsplit, int64_t n, double* B,
                          hipStream_t st) {
-  const int64_t blocks = (n + 255) / 256;
+  const int64_t blocks = (n + 15) / 16;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)blocks), dim3(256), 0, st, partial, nsplit, n, B,
                      static_cast<int*>(pl->flag.p));
   HIPCHK(hipGetLastError());
@@ -231,21 +248,24 @@ static int launch_reduce(temx_plan* pl, const double* partial, int nsplit, int64
 
 static int launch_solve(temx_plan* pl, const double* B, int NF, int64_t D, double* C, double* Xb,
                         hipStream_t st) {
-  dim3 grid((unsigned)((D + 15) / 16), NF);
+  // slices of the output latitudes so that small problems still give >= ~2 blocks per CU
+  const int64_t base = ((D + 15) / 16) * NF;
+  int ms = Xb ? (int)std::min<int64_t>(12, std::max<int64_t>(1, (2 * pl->num_cu + base - 1) / base)) : 1;
+  dim3 grid((unsigned)((D + 15) / 16), NF, ms);
   hipLaunchKernelGGL(solve_kernel, grid, dim3(256), 0, st, B, pl->K, pl->K4, pl->M, D, pl->Ginv.d(),
                      pl->Y0p.d(), C, Xb);
   HIPCHK(hipGetLastError());
   return TEMX_OK;
 }
 
-template <typename T, int MODE>
-static int launch_eddy_t(temx_plan* pl, const FieldPtrs<4>& fp, double* partial, const Split& sp,
+template <typename T, int MODE, int DPW>
+static int launch_eddy_d(temx_plan* pl, const FieldPtrs<4>& fp, double* partial, const Split& sp,
                          const EddyOut& eo, hipStream_t st) {
   dim3 grid(sp.grid), block(512);
 #define TEMX_LE(TBv)                                                                                  \
   do {                                                                                                \
-    auto kern = eddy_kernel<T, TBv, MODE>;                                                            \
-    const size_t lds = ((size_t)4 * 4 * TBv * 64 + 8 * EDDY_GR * TBv * 16) * sizeof(double);          \
+    auto kern = eddy_kernel<T, TBv, MODE, DPW>;                                                       \
+    const size_t lds = ((size_t)DPW * 4 * TBv * 64 + 8 * EDDY_GR * TBv * 16) * sizeof(double);        \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
     hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->N, pl->D, pl->K, pl->yblk.d(),             \
@@ -260,6 +280,16 @@ static int launch_eddy_t(temx_plan* pl, const FieldPtrs<4>& fp, double* partial,
 #undef TEMX_LE
   HIPCHK(hipGetLastError());
   return TEMX_OK;
+}
+
+template <typename T, int MODE>
+static int launch_eddy_t(temx_plan* pl, const FieldPtrs<4>& fp, double* partial, const Split& sp,
+                         const EddyOut& eo, hipStream_t st) {
+  switch (sp.dpw) {
+    case 1: return launch_eddy_d<T, MODE, 1>(pl, fp, partial, sp, eo, st);
+    case 2: return launch_eddy_d<T, MODE, 2>(pl, fp, partial, sp, eo, st);
+    default: return launch_eddy_d<T, MODE, 4>(pl, fp, partial, sp, eo, st);
+  }
 }
 
 static int launch_recon(temx_plan* pl, int64_t D, const double* C, double* out, hipStream_t st) {
@@ -632,11 +662,15 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
   }
   if ((rc = upload(pl->colscale, cs.data(), cs.size() * 8))) return rc;
 
-  pl->sp_proj4 = choose_split(D, pl->nchunk, proj_wps(4) * pl->num_cu, proj_dpw(4));
-  // eddy sweep: one 8-wave workgroup per CU (LDS slab), each work id is shared by two waves that
-  // halve its chunk range -> 2 partial slabs per split
-  pl->sp_eddy = choose_split(D, pl->nchunk / 2, pl->num_cu);
-  const size_t need = (size_t)std::max(pl->sp_proj4.nsplit * 4, pl->sp_eddy.nsplit * 2 * 3) * pl->K * D * 8;
+  const int ndt_ = (int)((D + 15) / 16);
+  const int pdpw = proj_dpw(4, ndt_);
+  pl->sp_proj4 = choose_split(D, pl->nchunk, proj_wps(4, pdpw) * pl->num_cu, pdpw);
+  // eddy sweep: one 8-wave workgroup per CU (LDS slabs) owning dpw d-tiles; the 8/dpw waves on a
+  // d-tile split its chunk range -> 8/dpw partial slabs per split
+  const int edpw = pick_dpw(ndt_, 4);
+  pl->sp_eddy = choose_split(D, pl->nchunk / (8 / edpw), pl->num_cu, edpw);
+  const size_t need =
+      (size_t)std::max(pl->sp_proj4.nsplit * 4, pl->sp_eddy.nsplit * (8 / edpw) * 3) * pl->K * D * 8;
   if ((rc = pl->partial.ensure(need))) return rc;
   if ((rc = pl->B4.ensure((size_t)4 * pl->K * D * 8))) return rc;
   if ((rc = pl->B3.ensure((size_t)3 * pl->K * D * 8))) return rc;
@@ -700,7 +734,8 @@ int temx_tem_stage2(temx_plan* pl, const void* ua, const void* va, const void* t
   rc = run_eddy(pl, ua, va, ta, wap, dtype, pl->partial.d(), nullptr, st);
   time_end(pl, 1, st, tl);
   if (rc) return rc;
-  return launch_reduce(pl, pl->partial.d(), pl->sp_eddy.nsplit * 2, (int64_t)3 * pl->K * pl->D, B3, st);
+  return launch_reduce(pl, pl->partial.d(), pl->sp_eddy.nsplit * (8 / pl->sp_eddy.dpw), (int64_t)3 * pl->K * pl->D, B3,
+                       st);
 }
 
 int temx_tem_stage3(temx_plan* pl, const double* B3, double* results, double* zonal, void* stream) {
