@@ -67,10 +67,11 @@ def cpu_baseline_and_parity(plan_factory, lat, lon, plev, nt_s, device):
         err = max(err, float(np.max(np.abs(res[i] - ref[n])) / np.max(np.abs(ref[n]))))
     plan.close()
     pts = lat.size * len(plev) * nt_s
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count()
+    try:    # threads the numpy/scipy BLAS actually used
+        from threadpoolctl import threadpool_info
+        cores = max([int(x.get("num_threads", 1)) for x in threadpool_info()] or [1])
+    except Exception:
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
     return {"value": pts / t_cpu, "unit": "grid-points/s", "cores": cores, "kind": "port",
             "sample": "ne%d grid (%d cols) x %d lev x %d of the snapshots, oracle/tem_oracle.py "
                       "factorised numpy restatement, %.1f s" % (0, lat.size, len(plev), nt_s, t_cpu)}, err, bad
@@ -86,6 +87,8 @@ def main():
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-nt", type=int, default=2)
+    ap.add_argument("--also", default="ne30x72x1",
+                    help="comma list of extra (small) workloads timed after the main one, N=1 only")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,6 +205,32 @@ def main():
                                    "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": gbs / PEAK_HBM_GBS, "avg_launch_ms": proj_ms,
                                    "mfma_tflops": 4 * 2 * K_HARM * pts_rank / (proj_ms * 1e-3) / 1e12}
+
+    if rank == 0 and world == 1 and args.also:
+        # other BASELINE.json shapes, same pipeline, reported beside the headline (not the metric)
+        rec["other_workloads"] = {}
+        for wl in [w for w in args.also.split(",") if w]:
+            ne2, nlev2, nt2 = parse_workload(wl)
+            lat2, lon2 = synth.cubed_sphere_gll(ne2)
+            plev2 = synth.pressure_levels(nlev2)
+            p2 = engine.Plan(lat2, lat_zm, K_HARM - 1, device=local_rank)
+            p2.set_tem(nlev2, nt2, plev2 * 100)
+            f2 = engine.synth_fields(local_rank, lat2, lon2, plev2, nt2, dtype=tdtype, seed=0)
+            o2 = p2._alloc_results(False)
+            for _ in range(5):
+                p2.tem_run(*f2, out=o2)
+            torch.cuda.synchronize()
+            reps = 50
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                p2.tem_run(*f2, out=o2)
+            torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t0) / reps
+            pts2 = lat2.size * nlev2 * nt2
+            rec["other_workloads"][wl] = {"ms_per_step": dt2 * 1e3, "grid_points_per_s": pts2 / dt2,
+                                          "frac_of_fp64_roofline": pts2 / dt2 / (PEAK_F64_TFLOPS * 1e12 / FLOPS_PER_PT)}
+            p2.close()
+            del f2, o2
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         del fields

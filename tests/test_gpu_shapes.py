@@ -1,0 +1,93 @@
+"""GPU parity at shapes that stress the decomposition (ragged ncol / D, several d-tiles per
+workgroup configurations, fp32 inputs) against the CPU oracle on the same seeded inputs, plus
+size-independent properties at a BASELINE-sized grid."""
+import numpy as np
+import pytest
+
+from conftest import fieldnorm_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def run_case(ne, nlev, nt, L=50, dtype=np.float64, seed=0):
+    from oracle import tem_oracle as orc
+    from pytemdiags_amd import _lib, engine, synth
+    lat, lon = synth.cubed_sphere_gll(ne)
+    plev = synth.pressure_levels(nlev)
+    f = synth.analytic_fields(lat, lon, plev, nt, seed=seed, dtype=dtype)
+    ref = orc.TEMOracle(*f, lat, plev, L=L, mode="factorised")
+    plan = engine.Plan(lat, ref.lat, L)
+    plan.set_tem(nlev, nt, plev * 100)
+    dev = [torch.as_tensor(x, device="cuda:0") for x in f]
+    res, zon = plan.tem_run(*dev, want_zonal=True)
+    assert not plan.status()
+    res, zon = res.cpu().numpy(), zon.cpu().numpy()
+    tol = 1e-10 if dtype == np.float64 else 2e-5
+    for i, n in enumerate(_lib.RESULT_NAMES):
+        e = fieldnorm_err(res[i], getattr(ref, n)())
+        assert e <= tol, (ne, nlev, nt, n, e)
+    for i, n in enumerate(_lib.ZONAL_NAMES):
+        e = fieldnorm_err(zon[i], getattr(ref, n))
+        assert e <= tol, (ne, nlev, nt, n, e)
+    plan.close()
+
+
+@pytest.mark.parametrize("ne,nlev,nt,L", [
+    (4, 7, 3, 50),      # D = 21: two d-tiles, ragged
+    (4, 2, 1, 50),      # D = 2: a single partial d-tile (nlev = 2 is the minimum np.gradient takes)
+    (8, 72, 1, 50),     # the ne30x72x1 shape in small: 5 d-tiles -> 1 d-tile per workgroup
+    (8, 16, 8, 50),     # D = 128: 8 d-tiles -> 4 per workgroup
+    (8, 9, 5, 15),      # TB = 4
+    (8, 12, 2, 31),     # TB = 8
+    (8, 12, 2, 60),     # TB = 16
+    (16, 24, 3, 50),    # D = 72 again with more columns per split
+])
+def test_pipeline_shapes_fp64(ne, nlev, nt, L):
+    run_case(ne, nlev, nt, L)
+
+
+def test_pipeline_fp32_inputs():
+    run_case(8, 30, 4, dtype=np.float32)
+
+
+def test_properties_at_baseline_grid_size():
+    """ne30 (48 602 columns) x 72 x 2: properties that need no CPU reference."""
+    from pytemdiags_amd import _lib, engine, synth
+    lat, lon = synth.cubed_sphere_gll(30)
+    plev = synth.pressure_levels(72)
+    lat_zm = (np.arange(-90, 91, 1.0)[1:] + np.arange(-90, 91, 1.0)[:-1]) / 2
+    plan = engine.Plan(lat, lat_zm, 50)
+    plan.set_tem(72, 2, plev * 100)
+    # (1) G^-1 G = I  (the sanity numbers the reference prints, sph_zonal_mean.py:393-398)
+    P = (plan.matrix(_lib.MAT_GINV) @ plan.matrix(_lib.MAT_GRAM)).cpu().numpy()
+    assert np.max(np.abs(P - np.eye(51))) < 1e-12
+    # (2) a zonally symmetric field (a function of latitude only, inside the span of the basis)
+    #     has zero eddies and is reproduced by both zonal means
+    Y0 = plan.matrix(_lib.MAT_Y0)
+    coef = torch.linspace(1.0, 0.1, 51, dtype=torch.float64, device="cuda:0")
+    sym = (Y0 @ coef)[:, None, None].expand(-1, 72, 2).contiguous()
+    zm_n = plan.zonal_mean(sym, native=True)
+    assert float((zm_n - sym).abs().max()) < 1e-11 * float(sym.abs().max())
+    Y0p = plan.matrix(_lib.MAT_Y0P)
+    zm = plan.zonal_mean(sym)
+    assert float((zm - (Y0p @ coef)[:, None, None]).abs().max()) < 1e-11
+    # (3) linearity of the operator:  zm(a x + b y) = a zm(x) + b zm(y)
+    f = engine.synth_fields(0, lat, lon, plev, 2)
+    lhs = plan.zonal_mean(2.5 * f[0] - 0.5 * f[1])
+    rhs = 2.5 * plan.zonal_mean(f[0]) - 0.5 * plan.zonal_mean(f[1])
+    assert float((lhs - rhs).abs().max()) < 1e-11 * float(rhs.abs().max())
+    # (4) idempotence on the native grid: zmn(zmn(x)) = zmn(x)
+    z1 = plan.zonal_mean(f[0], native=True)
+    z2 = plan.zonal_mean(z1, native=True)
+    assert float((z2 - z1).abs().max()) < 1e-11 * float(z1.abs().max())
+    # (5) symmetric inputs -> zero eddy fluxes; the pipeline still runs (psi = 0/.. guarded by T)
+    res, zon = plan.tem_run(sym, sym, f[2], sym, want_zonal=True)
+    assert not plan.status()
+    scale = float(sym.abs().max()) ** 2
+    assert float(zon[_lib.ZONAL_NAMES.index("upvpb")].abs().max()) < 1e-18 * scale + 1e-20
+    # (6) run-to-run determinism (fixed-order reductions)
+    r1, _ = plan.tem_run(*f)
+    r2, _ = plan.tem_run(*f)
+    assert torch.equal(r1, r2)
+    plan.close()
