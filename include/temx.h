@@ -148,6 +148,29 @@ int temx_tem_run(temx_plan* plan, const void* ua, const void* va, const void* ta
 int temx_tem_eddy(temx_plan* plan, const void* ua, const void* va, const void* ta,
                   const void* wap, int dtype, double* const* eddy_ptrs_host, void* stream);
 
+/* ---- tracer TEM (Abalos+ 2017): replaces the tracer parts of _decompose_zm_eddy, _compute_fluxes,
+ * _compute_derivatives (tem_diagnostics.py:532-538, 560-570, 602-611) and etfy ... qtendwtem
+ * (:801-991) for ONE tracer q [ncol][D].  Needs the plan state of a preceding temx_tem_run /
+ * temx_tem_stage3 on the same fields (coefficients of v and omega, psi, vtem, omegatem).
+ * Staged like the TEM pipeline so that ncol-sharded callers can all-reduce the raw sums:
+ *   stage1: Bq[K][D]    = Y0^T q
+ *   stage2: Bq2[2][K][D] = Y0^T {q'v', q'w'}   (one sweep: reconstruct qbar, vbar, wbar)
+ *   stage3: tres[TEMX_NTRES][M][D] fp64, tzon NULL or [TEMX_NTZON][M][D] fp64. */
+enum { TEMX_T_ETFY = 0, TEMX_T_ETFZ, TEMX_T_ETDIV, TEMX_T_QTENDETFD, TEMX_T_QTENDVTEM, TEMX_T_QTENDWTEM,
+       TEMX_NTRES };
+enum { TEMX_TZ_QB = 0, TEMX_TZ_QPVPB, TEMX_TZ_QPWAPPB, TEMX_TZ_DQB_DP, TEMX_TZ_QBCOSLAT,
+       TEMX_TZ_DQBCOSLAT_DLAT, TEMX_NTZON };
+int temx_tracer_stage1(temx_plan* plan, const void* q, int dtype, double* Bq, void* stream);
+int temx_tracer_stage2(temx_plan* plan, const void* q, const void* va, const void* wap, int dtype,
+                       const double* Bq, double* Bq2, void* stream);
+int temx_tracer_stage3(temx_plan* plan, const double* Bq2, double* tres, double* tzon, void* stream);
+int temx_tracer_run(temx_plan* plan, const void* q, const void* va, const void* wap, int dtype,
+                    double* tres, double* tzon, void* stream);
+/* lazily materialise qp, qpvp, qpwapp ([ncol][D] fp64 each; NULL entries skipped) of the tracer
+ * whose temx_tracer_stage2 / run was the last one on this plan (tem_diagnostics.py:537, 563-567). */
+int temx_tracer_eddy(temx_plan* plan, const void* q, const void* va, const void* wap, int dtype,
+                     double* const* ptrs3_host, void* stream);
+
 /* Synchronises the stream and reports whether any non-finite value reached the zonal sums
  * since the last call (the reference raises on NaN input, sph_zonal_mean.py:219-221). */
 int temx_status(temx_plan* plan, int* nonfinite, void* stream);

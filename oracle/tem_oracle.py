@@ -205,6 +205,9 @@ ZONAL_ATTRS = ("ub", "vb", "thetab", "wapb", "upvpb", "upwappb", "vptpb", "dub_d
 NATIVE_ATTRS = ("up", "vp", "thetap", "wapp", "upvp", "upwapp", "vptp")
 RESULTS = ("vtem", "omegatem", "wtem", "psitem", "epfy", "epfz", "epdiv",
            "utendepfd", "utendvtem", "utendwtem")
+TRACER_RESULTS = ("etfy", "etfz", "etdiv", "qtendetfd", "qtendvtem", "qtendwtem")
+TRACER_ZONAL = ("qb", "qpvpb", "qpwappb", "dqb_dp", "qbcoslat", "dqbcoslat_dlat")
+TRACER_NATIVE = ("qp", "qpvp", "qpwapp")
 
 
 class TEMOracle:
@@ -214,11 +217,14 @@ class TEMOracle:
     """
 
     def __init__(self, ua, va, ta, wap, lat_native, plev, p0=P0, zm_dlat=1, L=50,
-                 zm_pole_points=False, mode="literal", basis="scipy"):
+                 zm_pole_points=False, mode="literal", basis="scipy", q=None):
         ua, va, ta, wap = (np.asarray(x) for x in (ua, va, ta, wap))
         plev = np.asarray(plev)
+        self.q = [] if q is None else [np.asarray(x) for x in (q if isinstance(q, (list, tuple)) else [q])]
+        self.ntrac = len(self.q)                                 # :281-299
         if plev[0] > plev[-1]:                                   # :372-382
             ua, va, ta, wap = (x[:, ::-1, :] for x in (ua, va, ta, wap))
+            self.q = [x[:, ::-1, :] for x in self.q]
             plev = plev[::-1]
         self.ua, self.va, self.ta, self.wap = ua, va, ta, wap
         self.plev = plev
@@ -245,6 +251,14 @@ class TEMOracle:
         self.upwapp = self.up * self.wapp;    self.upwappb = zm(self.upwapp)
         self.vptp = self.vp * self.thetap;    self.vptpb = zm(self.vptp)
 
+        # tracers  (:532-538, :560-570)
+        self.qb = [zm(x) for x in self.q]
+        self.qp = [x - zmn(x) for x in self.q]
+        self.qpvp = [x * self.vp for x in self.qp]
+        self.qpvpb = [zm(x) for x in self.qpvp]
+        self.qpwapp = [x * self.wapp for x in self.qp]
+        self.qpwappb = [zm(x) for x in self.qpwapp]
+
         self._derivatives()
 
     @classmethod
@@ -261,6 +275,7 @@ class TEMOracle:
         self.coslat = np.cos(self.lat * np.pi / 180)
         for n in ("ub", "vb", "thetab", "wapb", "upvpb", "upwappb", "vptpb"):
             setattr(self, n, np.asarray(zonal[n]))
+        self.q = []
         self.ua = np.empty(0, dtype=ua_dtype)
         self.va = np.empty(0, dtype=va_dtype)
         self.wap = np.empty(0, dtype=wap_dtype)
@@ -279,6 +294,11 @@ class TEMOracle:
         self.dpsicoslat_dlat = lat_gradient(self.psicoslat, latr)
         self.dpsi_dp = p_gradient(self.psi, self.p)
         self.int_vbdp = p_integral(self.vb, self.p)
+        # tracer derivatives (:602-611)
+        qb = getattr(self, "qb", [])
+        self.dqb_dp = [p_gradient(x, self.p) for x in qb]
+        self.qbcoslat = [multiply_lat(x, self.coslat) for x in qb]
+        self.dqbcoslat_dlat = [lat_gradient(x, latr) for x in self.qbcoslat]
 
     # ---- diagnostics (each cast to an input dtype exactly where the reference does) ----
     def vtem(self):          # :615-628
@@ -318,6 +338,34 @@ class TEMOracle:
 
     def utendwtem(self):     # :783-797
         return (-self.omegatem() * self.dub_dp).astype(self.ua.dtype)
+
+    # ---- tracer TEM (Abalos+ 2017), tem_diagnostics.py:801-991 ----
+    def etfy(self, qi=0):        # :801-830
+        x = multiply_lat(self.dqb_dp[qi] * self.psi - self.qpvpb[qi], a * self.coslat)
+        return multiply_p(x, self.p / self.p0).astype(self.q[qi].dtype)
+
+    def etfz(self, qi=0):        # :834-863
+        x = -multiply_lat(self.dqbcoslat_dlat[qi], 1 / (a * self.coslat))
+        return (-H / self.p0 * multiply_lat((x * self.psi - self.qpwappb[qi]), a * self.coslat)).astype(self.q[qi].dtype)
+
+    def etdiv(self, qi=0):       # :867-899
+        Mphi = multiply_p(self.etfy(qi), self.p0 / self.p)
+        Mp = self.etfz(qi) * -self.p0 / H
+        dM = lat_gradient(multiply_lat(Mphi, self.coslat), np.deg2rad(self.lat))
+        return (multiply_lat(dM, 1 / (a * self.coslat)) + p_gradient(Mp, self.p)).astype(self.q[qi].dtype)
+
+    def qtendetfd(self, qi=0):   # :903-927
+        return multiply_lat(self.etdiv(qi), 1 / (a * self.coslat)).astype(self.q[qi].dtype)
+
+    def qtendvtem(self, qi=0):   # :931-959
+        diff = multiply_lat(self.dqbcoslat_dlat[qi], 1 / (a * self.coslat))
+        return (-self.vtem() * diff).astype(self.q[qi].dtype)
+
+    def qtendwtem(self, qi=0):   # :963-991  (NB: uses omegatem, not wtem -- SURVEY Q11)
+        return (-self.omegatem() * self.dqb_dp[qi]).astype(self.q[qi].dtype)
+
+    def tracer_results(self, qi=0):
+        return {n: getattr(self, n)(qi) for n in TRACER_RESULTS}
 
     def results(self):
         return {n: getattr(self, n)() for n in RESULTS}

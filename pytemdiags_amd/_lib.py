@@ -21,6 +21,9 @@ ZONAL_NAMES = ("ub", "vb", "thetab", "wapb", "upvpb", "upwappb", "vptpb", "dub_d
                "ubcoslat", "dubcoslat_dlat", "psi", "psicoslat", "dpsicoslat_dlat", "dpsi_dp",
                "int_vbdp")
 EDDY_NAMES = ("up", "vp", "thetap", "wapp", "upvp", "upwapp", "vptp")
+TRACER_RESULT_NAMES = ("etfy", "etfz", "etdiv", "qtendetfd", "qtendvtem", "qtendwtem")
+TRACER_ZONAL_NAMES = ("qb", "qpvpb", "qpwappb", "dqb_dp", "qbcoslat", "dqbcoslat_dlat")
+TRACER_EDDY_NAMES = ("qp", "qpvp", "qpwapp")
 
 ERRORS = {0: "TEMX_OK", -1: "TEMX_EINVAL", -2: "TEMX_EHIP", -3: "TEMX_ENOMEM", -4: "TEMX_ERANK",
           -5: "TEMX_ESTATE", -6: "TEMX_EUNSUPPORTED"}
@@ -45,6 +48,11 @@ SIGNATURES = [
     ("temx_tem_stage3", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("temx_tem_run", _i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     ("temx_tem_eddy", _i, [_vp, _vp, _vp, _vp, _vp, _i, C.POINTER(_vp), _vp]),
+    ("temx_tracer_stage1", _i, [_vp, _vp, _i, _vp, _vp]),
+    ("temx_tracer_stage2", _i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    ("temx_tracer_stage3", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("temx_tracer_run", _i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    ("temx_tracer_eddy", _i, [_vp, _vp, _vp, _vp, _i, C.POINTER(_vp), _vp]),
     ("temx_status", _i, [_vp, C.POINTER(_i), _vp]),
     ("temx_synth_fields", _i, [_i, _i64, _i, _i64, _i64, _vp, _vp, _vp, _i, _u64, _vp, _vp, _vp, _vp, _vp]),
     ("temx_mfma_f64_peak", _i, [_i, _i, _dp]),

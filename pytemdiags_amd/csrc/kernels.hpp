@@ -334,7 +334,9 @@ solve_kernel(const double* __restrict__ B, int K, int K4, int M, int64_t D,
 // ------------------------------------------------------------------------------------------------
 constexpr int EDDY_GR = 2;   // groups (of 4 columns) per eddy step: 8 columns x 16 (lev,time)
 
-template <typename T, int TB, int MODE, int DPW>
+// KIND 0: TEM      fields (u, v, T->theta, omega); products u'v', u'w', v'theta'
+// KIND 1: tracer   fields (q, v, omega);           products q'v', q'w'   (tem_diagnostics.py:532-538, 560-570)
+template <typename T, int TB, int MODE, int DPW, int KIND>
 __global__ void __launch_bounds__(512, 2)
 eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restrict__ yblk,
             int64_t nchunk, const double* __restrict__ colscale,
@@ -354,6 +356,8 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
   constexpr int YE = GR * TB * 16;           // doubles of Y0 blocks per step
   constexpr int YJ = (YE + 63) / 64;         // staging loads per lane
   constexpr int NP = 8 / DPW;
+  constexpr int NFR = KIND == 0 ? 4 : 3;     // fields reconstructed
+  constexpr int NPR = KIND == 0 ? 3 : 2;     // products projected
   int split, dq;
   if (!wg_work((ndt + DPW - 1) / DPW, nsplit, split, dq)) return;
   const int wave = uniform_wave(), lane = threadIdx.x & 63;
@@ -371,27 +375,27 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
   // coefficient B operands: cb[f][s][lane] = C_f[4 s + g][d]; all NP waves on the d-tile write
   // identical values (no barrier needed)
   {
-    double* cb = lds + (size_t)w4 * (4 * TB * 64) + lane;
+    double* cb = lds + (size_t)w4 * (NFR * TB * 64) + lane;
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < NFR; ++f)
 #pragma unroll
       for (int s = 0; s < TB; ++s) cb[(f * TB + s) * 64] = C[((int64_t)f * 4 * TB + 4 * s + g) * D + dcl];
   }
-  int cbi = w4 * (4 * TB * 64) + lane;   // index of this lane's first slab element in lds[]
-  double* yst = lds + DPW * 4 * TB * 64 + wave * YE;   // this wave's copy of the step's Y0 blocks
+  int cbi = w4 * (NFR * TB * 64) + lane;   // index of this lane's first slab element in lds[]
+  double* yst = lds + DPW * NFR * TB * 64 + wave * YE;   // this wave's copy of the step's Y0 blocks
 
-  const double sth = colscale != nullptr ? colscale[dcl] : 1.0;
+  const double sth = (KIND == 0 && colscale != nullptr) ? colscale[dcl] : 1.0;
   const uint32_t loff = (uint32_t)(g * D + dcl);
   const uint32_t aoff_r = (uint32_t)((lane & 3) * 4 + g);   // reconstruction A[i -> column][k -> harmonic]
   const uint32_t aoff_p = (uint32_t)(g * 4 + (lane & 3));   // projection     A[i -> harmonic][k -> column]
 
-  double acc[3][TB];
+  double acc[NPR][TB];
 #pragma unroll
-  for (int q = 0; q < 3; ++q)
+  for (int q = 0; q < NPR; ++q)
 #pragma unroll
     for (int t = 0; t < TB; ++t) acc[q][t] = 0.0;
 
-  T xn[4][GR];
+  T xn[NFR][GR];
   double ys[YJ];
   const int nfull = (int)(N / (4 * GR));     // steps whose rows all exist
   auto load_x = [&](int step, auto fastc) __attribute__((always_inline)) {
@@ -400,12 +404,12 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
       const int64_t gb = ((int64_t)step * GR + ti) * 4;
       if (decltype(fastc)::value) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) xn[f][ti] = (reinterpret_cast<const T*>(fp.p[f]) + gb * D)[loff];
+        for (int f = 0; f < NFR; ++f) xn[f][ti] = (reinterpret_cast<const T*>(fp.p[f]) + gb * D)[loff];
       } else {
         int64_t row = gb + g;
         row = row < N ? row : N - 1;
 #pragma unroll
-        for (int f = 0; f < 4; ++f) xn[f][ti] = reinterpret_cast<const T*>(fp.p[f])[row * D + dcl];
+        for (int f = 0; f < NFR; ++f) xn[f][ti] = reinterpret_cast<const T*>(fp.p[f])[row * D + dcl];
       }
     }
   };
@@ -424,13 +428,15 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
     const bool more = FAST || step + 1 < c1;
     if (more) load_ys(step + 1);
 
-    double xs[4][GR];
+    double xs[NFR][GR];
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < NFR; ++f)
 #pragma unroll
       for (int ti = 0; ti < GR; ++ti) xs[f][ti] = (double)xn[f][ti];
+    if (KIND == 0) {
 #pragma unroll
-    for (int ti = 0; ti < GR; ++ti) xs[2][ti] *= sth;
+      for (int ti = 0; ti < GR; ++ti) xs[2][ti] *= sth;
+    }
     if (more) load_x(step + 1, fastc);
 
     // The slab is loop invariant: without this, hipcc hoists all 4*TB LDS reads out of the loop
@@ -439,44 +445,53 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
     const double* cbr = lds + cbi;
 
     // ---- reconstruction: rec[f][ti] = sum_s Y0blk[ti][s] . C_f[s] ----
-    double rec[4][GR];
+    double rec[NFR][GR];
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < NFR; ++f)
 #pragma unroll
       for (int ti = 0; ti < GR; ++ti) rec[f][ti] = 0.0;
 #pragma unroll
     for (int s = 0; s < TB; ++s) {
-      double cbc[4];
+      double cbc[NFR];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) cbc[f] = cbr[(f * TB + s) * 64];
+      for (int f = 0; f < NFR; ++f) cbc[f] = cbr[(f * TB + s) * 64];
 #pragma unroll
       for (int ti = 0; ti < GR; ++ti) {
         const double ya = yst[(ti * TB + s) * 16 + aoff_r];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) rec[f][ti] = TEMX_MFMA4(ya, cbc[f], rec[f][ti]);
+        for (int f = 0; f < NFR; ++f) rec[f][ti] = TEMX_MFMA4(ya, cbc[f], rec[f][ti]);
       }
     }
 
-    // ---- eddies and products (tem_diagnostics.py:517-529, 547-555) ----
-    double p[3][GR];
+    // ---- eddies and products (tem_diagnostics.py:517-529, 547-555; tracers :537, :563-567) ----
+    double p[NPR][GR];
 #pragma unroll
     for (int ti = 0; ti < GR; ++ti) {
-      const double eu = xs[0][ti] - rec[0][ti], ev = xs[1][ti] - rec[1][ti];
-      const double eth = xs[2][ti] - rec[2][ti], ew = xs[3][ti] - rec[3][ti];
-      p[0][ti] = eu * ev;    // u'v'
-      p[1][ti] = eu * ew;    // u'w'
-      p[2][ti] = ev * eth;   // v'theta'
+      double e[NFR];
+#pragma unroll
+      for (int f = 0; f < NFR; ++f) e[f] = xs[f][ti] - rec[f][ti];
+      if (KIND == 0) {
+        p[0][ti] = e[0] * e[1];                    // u'v'
+        p[1][ti] = e[0] * e[NFR - 1];              // u'w'
+        p[NPR - 1][ti] = e[1] * e[2];              // v'theta'
+      } else {
+        p[0][ti] = e[0] * e[1];                    // q'v'
+        p[1][ti] = e[0] * e[2];                    // q'w'
+      }
       if (MODE == 1) {
         const int64_t row = ((int64_t)step * GR + ti) * 4 + g;
         if (dvalid && row < N) {
           const int64_t o = row * D + d;
-          if (eo.p[0]) eo.p[0][o] = eu;
-          if (eo.p[1]) eo.p[1][o] = ev;
-          if (eo.p[2]) eo.p[2][o] = eth;
-          if (eo.p[3]) eo.p[3][o] = ew;
-          if (eo.p[4]) eo.p[4][o] = p[0][ti];
-          if (eo.p[5]) eo.p[5][o] = p[1][ti];
-          if (eo.p[6]) eo.p[6][o] = p[2][ti];
+          if (KIND == 0) {
+#pragma unroll
+            for (int f = 0; f < NFR; ++f)
+              if (eo.p[f]) eo.p[f][o] = e[f];
+          } else if (eo.p[0]) {
+            eo.p[0][o] = e[0];
+          }
+#pragma unroll
+          for (int q = 0; q < NPR; ++q)
+            if (eo.p[4 + q]) eo.p[4 + q][o] = p[q][ti];
         }
       }
     }
@@ -488,7 +503,7 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
       for (int t = 0; t < TB; ++t) {
         const double ya = yst[(ti * TB + t) * 16 + aoff_p];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) acc[q][t] = TEMX_MFMA4(ya, p[q][ti], acc[q][t]);
+        for (int q = 0; q < NPR; ++q) acc[q][t] = TEMX_MFMA4(ya, p[q][ti], acc[q][t]);
       }
   };
 
@@ -505,11 +520,11 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
   if (dvalid && partial != nullptr) {
     const int64_t slab = sub;
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < NPR; ++q)
 #pragma unroll
       for (int t = 0; t < TB; ++t) {
         const int l = t * 4 + g;
-        if (l < K) partial[((slab * 3 + q) * K + l) * D + d] = acc[q][t];
+        if (l < K) partial[((slab * NPR + q) * K + l) * D + d] = acc[q][t];
       }
   }
 }
@@ -691,6 +706,94 @@ tem_epilogue_kernel(const double* __restrict__ zb, int M, int nlev, int64_t nt, 
     zon[13 * MD + idx] = dpsicos_dlat;
     zon[14 * MD + idx] = dpsi_dp;
     zon[15 * MD + idx] = at(intv, m, j);
+  }
+}
+
+// Tracer TEM epilogue (Abalos+ 2017; tem_diagnostics.py:602-611, 801-991).  One thread per zonal
+// grid point, stencils recomputed like tem_epilogue_kernel.
+// zb: the TEM zonal means of the plan ([8][M][D]); tz: [3][M][D] = qb qpvpb qpwappb.
+// tres: [6][M][D] = etfy etfz etdiv qtendetfd qtendvtem qtendwtem;
+// tzon: NULL or [6][M][D] = qb qpvpb qpwappb dqb_dp qbcoslat dqbcoslat_dlat.
+__global__ void __launch_bounds__(256)
+tracer_epilogue_kernel(const double* __restrict__ zb, const double* __restrict__ tz, int M, int nlev,
+                       int64_t nt, EpiTables tb, double p0, double* __restrict__ tres,
+                       double* __restrict__ tzon) {
+  constexpr double a_e = 6.37123e6, Hs = 7000.0;
+  const int64_t D = (int64_t)nlev * nt;
+  const int64_t MD = (int64_t)M * D;
+  const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (idx >= MD) return;
+  const int m = (int)(idx / D);
+  const int64_t dd = idx % D;
+  const int j = (int)(dd / nt);
+  const int64_t t = dd % nt;
+  const double* vb = zb + MD;
+  const double* thb = zb + 2 * MD;
+  const double* wb = zb + 3 * MD;
+  const double* vptpb = zb + 6 * MD;
+  const double* qb = tz;
+  const double* qpvpb = tz + MD;
+  const double* qpwb = tz + 2 * MD;
+
+  auto at = [&](const double* A, int mm, int jj) { return A[((int64_t)mm * nlev + jj) * nt + t]; };
+  auto clj = [&](int jj) { return jj < 0 ? 0 : (jj >= nlev ? nlev - 1 : jj); };
+  auto clm = [&](int mm) { return mm < 0 ? 0 : (mm >= M ? M - 1 : mm); };
+  auto ddp = [&](const double* A, int mm, int jj) {
+    return tb.pg[jj * 3 + 0] * at(A, mm, clj(jj - 1)) + tb.pg[jj * 3 + 1] * at(A, mm, jj) +
+           tb.pg[jj * 3 + 2] * at(A, mm, clj(jj + 1));
+  };
+  auto psi_at = [&](int mm, int jj) { return at(vptpb, mm, jj) / ddp(thb, mm, jj); };
+  auto dqbcos_dlat = [&](int mm, int jj) {                              // :608-610
+    const int ma = clm(mm - 1), mb = clm(mm + 1);
+    return tb.lg[mm * 3 + 0] * (at(qb, ma, jj) * tb.coslat[ma]) +
+           tb.lg[mm * 3 + 1] * (at(qb, mm, jj) * tb.coslat[mm]) +
+           tb.lg[mm * 3 + 2] * (at(qb, mb, jj) * tb.coslat[mb]);
+  };
+  auto etfy_at = [&](int mm, int jj, double ps) {                       // :823-824
+    const double x = (ddp(qb, mm, jj) * ps - at(qpvpb, mm, jj)) * (a_e * tb.coslat[mm]);
+    return x * (tb.p[jj] / p0);
+  };
+  auto etfz_at = [&](int mm, int jj, double ps) {                       // :856-857
+    const double x = -(dqbcos_dlat(mm, jj) * (1.0 / (a_e * tb.coslat[mm])));
+    return -Hs / p0 * ((x * ps - at(qpwb, mm, jj)) * (a_e * tb.coslat[mm]));
+  };
+
+  const int jm = clj(j - 1), jp = clj(j + 1), mm1 = clm(m - 1), mp1 = clm(m + 1);
+  const double cosm = tb.coslat[m];
+  const double inv_acos = 1.0 / (a_e * cosm);
+  const double psi0 = psi_at(m, j);
+  const double psi_jm = psi_at(m, jm), psi_jp = psi_at(m, jp);
+  const double psi_mm = psi_at(mm1, j), psi_mp = psi_at(mp1, j);
+  const double dpsi_dp = tb.pg[j * 3 + 0] * psi_jm + tb.pg[j * 3 + 1] * psi0 + tb.pg[j * 3 + 2] * psi_jp;
+  const double dpsicos_dlat = tb.lg[m * 3 + 0] * (psi_mm * tb.coslat[mm1]) + tb.lg[m * 3 + 1] * (psi0 * cosm) +
+                              tb.lg[m * 3 + 2] * (psi_mp * tb.coslat[mp1]);
+  const double vtem = at(vb, m, j) - dpsi_dp;                            // :622
+  const double omegatem = at(wb, m, j) + dpsicos_dlat * inv_acos;        // :639
+  const double dqb_dp = ddp(qb, m, j);
+  const double dqbcos = dqbcos_dlat(m, j);
+
+  const double etfy = etfy_at(m, j, psi0);
+  const double etfz = etfz_at(m, j, psi0);
+  const double p0_p = p0 / tb.p[j];                                      // :887-893
+  const double dM = tb.lg[m * 3 + 0] * (etfy_at(mm1, j, psi_mm) * p0_p * tb.coslat[mm1]) +
+                    tb.lg[m * 3 + 1] * (etfy * p0_p * cosm) +
+                    tb.lg[m * 3 + 2] * (etfy_at(mp1, j, psi_mp) * p0_p * tb.coslat[mp1]);
+  const double dMp = tb.pg[j * 3 + 0] * (etfz_at(m, jm, psi_jm) * -p0 / Hs) + tb.pg[j * 3 + 1] * (etfz * -p0 / Hs) +
+                     tb.pg[j * 3 + 2] * (etfz_at(m, jp, psi_jp) * -p0 / Hs);
+  const double etdiv = dM * inv_acos + dMp;
+  tres[0 * MD + idx] = etfy;
+  tres[1 * MD + idx] = etfz;
+  tres[2 * MD + idx] = etdiv;
+  tres[3 * MD + idx] = etdiv * inv_acos;                                 // qtendetfd :921
+  tres[4 * MD + idx] = -vtem * (dqbcos * inv_acos);                      // qtendvtem :952-953
+  tres[5 * MD + idx] = -omegatem * dqb_dp;                               // qtendwtem :984-985
+  if (tzon != nullptr) {
+    tzon[0 * MD + idx] = at(qb, m, j);
+    tzon[1 * MD + idx] = at(qpvpb, m, j);
+    tzon[2 * MD + idx] = at(qpwb, m, j);
+    tzon[3 * MD + idx] = dqb_dp;
+    tzon[4 * MD + idx] = at(qb, m, j) * cosm;
+    tzon[5 * MD + idx] = dqbcos;
   }
 }
 

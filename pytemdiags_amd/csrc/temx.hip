@@ -90,6 +90,8 @@ struct temx_plan {
   double p0 = 101325.0;
   DevBuf p, pg, lg, coslat, fcor, colscale;
   DevBuf B4, B3, C4, zb;
+  DevBuf Bq, Bq2, Ct, tz;          // tracer workspace: sums, coefficients (q, v, w), zonal means
+  Split sp_proj1, sp_eddy_t;
   Split sp_proj4, sp_eddy;
   // shared workspaces
   DevBuf partial;
@@ -258,18 +260,19 @@ static int launch_solve(temx_plan* pl, const double* B, int NF, int64_t D, doubl
   return TEMX_OK;
 }
 
-template <typename T, int MODE, int DPW>
-static int launch_eddy_d(temx_plan* pl, const FieldPtrs<4>& fp, double* partial, const Split& sp,
-                         const EddyOut& eo, hipStream_t st) {
+template <typename T, int MODE, int DPW, int KIND>
+static int launch_eddy_d(temx_plan* pl, const FieldPtrs<4>& fp, const double* C, double* partial,
+                         const Split& sp, const EddyOut& eo, hipStream_t st) {
   dim3 grid(sp.grid), block(512);
+  constexpr int NFR = KIND == 0 ? 4 : 3;
 #define TEMX_LE(TBv)                                                                                  \
   do {                                                                                                \
-    auto kern = eddy_kernel<T, TBv, MODE, DPW>;                                                       \
-    const size_t lds = ((size_t)DPW * 4 * TBv * 64 + 8 * EDDY_GR * TBv * 16) * sizeof(double);        \
+    auto kern = eddy_kernel<T, TBv, MODE, DPW, KIND>;                                                 \
+    const size_t lds = ((size_t)DPW * NFR * TBv * 64 + 8 * EDDY_GR * TBv * 16) * sizeof(double);      \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
     hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->N, pl->D, pl->K, pl->yblk.d(),             \
-                       pl->nchunk, pl->colscale.d(), pl->C4.d(), partial, sp.nsplit, sp.ndt, eo);     \
+                       pl->nchunk, pl->colscale.d(), C, partial, sp.nsplit, sp.ndt, eo);              \
   } while (0)
   switch (pl->TB) {
     case 4: TEMX_LE(4); break;
@@ -282,13 +285,13 @@ static int launch_eddy_d(temx_plan* pl, const FieldPtrs<4>& fp, double* partial,
   return TEMX_OK;
 }
 
-template <typename T, int MODE>
-static int launch_eddy_t(temx_plan* pl, const FieldPtrs<4>& fp, double* partial, const Split& sp,
-                         const EddyOut& eo, hipStream_t st) {
+template <typename T, int MODE, int KIND>
+static int launch_eddy_t(temx_plan* pl, const FieldPtrs<4>& fp, const double* C, double* partial,
+                         const Split& sp, const EddyOut& eo, hipStream_t st) {
   switch (sp.dpw) {
-    case 1: return launch_eddy_d<T, MODE, 1>(pl, fp, partial, sp, eo, st);
-    case 2: return launch_eddy_d<T, MODE, 2>(pl, fp, partial, sp, eo, st);
-    default: return launch_eddy_d<T, MODE, 4>(pl, fp, partial, sp, eo, st);
+    case 1: return launch_eddy_d<T, MODE, 1, KIND>(pl, fp, C, partial, sp, eo, st);
+    case 2: return launch_eddy_d<T, MODE, 2, KIND>(pl, fp, C, partial, sp, eo, st);
+    default: return launch_eddy_d<T, MODE, 4, KIND>(pl, fp, C, partial, sp, eo, st);
   }
 }
 
@@ -377,6 +380,27 @@ static void gradient_table(const std::vector<double>& x, std::vector<double>& ta
 
 static inline hipStream_t S_(void* s) { return static_cast<hipStream_t>(s); }
 
+template <int KIND>
+static int run_eddy(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, const double* C, double* partial,
+                    const EddyOut* eo, hipStream_t st) {
+  EddyOut none{};
+  if (dtype == TEMX_F64) {
+    return eo ? launch_eddy_t<double, 1, KIND>(pl, fp, C, partial, pl->sp_eddy, *eo, st)
+              : launch_eddy_t<double, 0, KIND>(pl, fp, C, partial, pl->sp_eddy, none, st);
+  }
+  if (dtype == TEMX_F32) {
+    return eo ? launch_eddy_t<float, 1, KIND>(pl, fp, C, partial, pl->sp_eddy, *eo, st)
+              : launch_eddy_t<float, 0, KIND>(pl, fp, C, partial, pl->sp_eddy, none, st);
+  }
+  return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
+}
+
+static FieldPtrs<4> four(const void* a, const void* b, const void* c, const void* d) {
+  FieldPtrs<4> fp;
+  fp.p[0] = a; fp.p[1] = b; fp.p[2] = c; fp.p[3] = d;
+  return fp;
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -397,7 +421,8 @@ void temx_plan_destroy(temx_plan* pl) {
   (void)hipSetDevice(pl->device);
   DevBuf* bufs[] = {&pl->x, &pl->Y0, &pl->yblk, &pl->yblk_w, &pl->Y0p, &pl->G, &pl->Ginv, &pl->norm,
                     &pl->flag, &pl->p, &pl->pg, &pl->lg, &pl->coslat, &pl->fcor, &pl->colscale,
-                    &pl->B4, &pl->B3, &pl->C4, &pl->zb, &pl->partial, &pl->opB, &pl->opC};
+                    &pl->B4, &pl->B3, &pl->C4, &pl->zb, &pl->partial, &pl->opB, &pl->opC,
+                    &pl->Bq, &pl->Bq2, &pl->Ct, &pl->tz};
   for (DevBuf* b : bufs) b->release();
   for (int w = 0; w < 2; ++w)
     for (auto& tl : pl->timed[w]) {
@@ -676,6 +701,7 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
   if ((rc = pl->B3.ensure((size_t)3 * pl->K * D * 8))) return rc;
   if ((rc = pl->C4.ensure((size_t)4 * pl->K4 * D * 8))) return rc;
   if ((rc = pl->zb.ensure((size_t)8 * M * D * 8))) return rc;
+  pl->sp_proj1 = choose_split(D, pl->nchunk, 2 * pl->num_cu);
   pl->tem = true;
   return TEMX_OK;
 }
@@ -704,22 +730,6 @@ int temx_tem_stage1(temx_plan* pl, const void* ua, const void* va, const void* t
   return launch_reduce(pl, pl->partial.d(), pl->sp_proj4.nsplit, (int64_t)4 * pl->K * pl->D, B4, st);
 }
 
-static int run_eddy(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap,
-                    int dtype, double* partial, const EddyOut* eo, hipStream_t st) {
-  FieldPtrs<4> fp;
-  fp.p[0] = ua; fp.p[1] = va; fp.p[2] = ta; fp.p[3] = wap;
-  EddyOut none{};
-  if (dtype == TEMX_F64) {
-    return eo ? launch_eddy_t<double, 1>(pl, fp, partial, pl->sp_eddy, *eo, st)
-              : launch_eddy_t<double, 0>(pl, fp, partial, pl->sp_eddy, none, st);
-  }
-  if (dtype == TEMX_F32) {
-    return eo ? launch_eddy_t<float, 1>(pl, fp, partial, pl->sp_eddy, *eo, st)
-              : launch_eddy_t<float, 0>(pl, fp, partial, pl->sp_eddy, none, st);
-  }
-  return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
-}
-
 int temx_tem_stage2(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap,
                     int dtype, const double* B4, double* B3, void* stream) {
   int rc = tem_ready(pl);
@@ -731,7 +741,7 @@ int temx_tem_stage2(temx_plan* pl, const void* ua, const void* va, const void* t
   if ((rc = launch_solve(pl, B4, 4, pl->D, pl->C4.d(), pl->zb.d(), st))) return rc;
   TimedLaunch tl{};
   time_begin(pl, 1, st, tl);
-  rc = run_eddy(pl, ua, va, ta, wap, dtype, pl->partial.d(), nullptr, st);
+  rc = run_eddy<0>(pl, four(ua, va, ta, wap), dtype, pl->C4.d(), pl->partial.d(), nullptr, st);
   time_end(pl, 1, st, tl);
   if (rc) return rc;
   return launch_reduce(pl, pl->partial.d(), pl->sp_eddy.nsplit * (8 / pl->sp_eddy.dpw), (int64_t)3 * pl->K * pl->D, B3,
@@ -776,7 +786,89 @@ int temx_tem_eddy(temx_plan* pl, const void* ua, const void* va, const void* ta,
   HIPCHK(hipSetDevice(pl->device));
   EddyOut eo;
   for (int i = 0; i < TEMX_NEDDY; ++i) eo.p[i] = eddy_ptrs_host[i];
-  return run_eddy(pl, ua, va, ta, wap, dtype, nullptr, &eo, S_(stream));
+  return run_eddy<0>(pl, four(ua, va, ta, wap), dtype, pl->C4.d(), nullptr, &eo, S_(stream));
+}
+
+// ---- tracer TEM -----------------------------------------------------------------------------------
+static int tracer_ws(temx_plan* pl) {
+  const int64_t D = pl->D;
+  int rc;
+  if ((rc = pl->Bq.ensure((size_t)pl->K * D * 8))) return rc;
+  if ((rc = pl->Bq2.ensure((size_t)2 * pl->K * D * 8))) return rc;
+  if ((rc = pl->Ct.ensure((size_t)3 * pl->K4 * D * 8))) return rc;
+  if ((rc = pl->tz.ensure((size_t)3 * pl->M * D * 8))) return rc;
+  const size_t need = (size_t)pl->sp_proj1.nsplit * pl->K * D * 8;
+  return pl->partial.ensure(std::max(need, pl->partial.bytes));
+}
+
+int temx_tracer_stage1(temx_plan* pl, const void* q, int dtype, double* Bq, void* stream) {
+  int rc = tem_ready(pl);
+  if (rc) return rc;
+  if (!q || !Bq) return fail(TEMX_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(pl->device));
+  if ((rc = tracer_ws(pl))) return rc;
+  FieldPtrs<1> fp;
+  fp.p[0] = q;
+  if ((rc = launch_project<1>(pl, fp, dtype, pl->D, nullptr, -1, pl->partial.d(), pl->sp_proj1, S_(stream)))) return rc;
+  return launch_reduce(pl, pl->partial.d(), pl->sp_proj1.nsplit, (int64_t)pl->K * pl->D, Bq, S_(stream));
+}
+
+int temx_tracer_stage2(temx_plan* pl, const void* q, const void* va, const void* wap, int dtype,
+                       const double* Bq, double* Bq2, void* stream) {
+  int rc = tem_ready(pl);
+  if (rc) return rc;
+  if (!q || !va || !wap || !Bq || !Bq2) return fail(TEMX_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(pl->device));
+  if ((rc = tracer_ws(pl))) return rc;
+  hipStream_t st = S_(stream);
+  const size_t slab = (size_t)pl->K4 * pl->D * 8;
+  // coefficients: Ct = (C_q, C_v, C_w); qb -> tz[0]
+  if ((rc = launch_solve(pl, Bq, 1, pl->D, pl->Ct.d(), pl->tz.d(), st))) return rc;
+  HIPCHK(hipMemcpyAsync((char*)pl->Ct.p + slab, (char*)pl->C4.p + slab, slab, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync((char*)pl->Ct.p + 2 * slab, (char*)pl->C4.p + 3 * slab, slab, hipMemcpyDeviceToDevice, st));
+  if ((rc = run_eddy<1>(pl, four(q, va, wap, nullptr), dtype, pl->Ct.d(), pl->partial.d(), nullptr, st))) return rc;
+  return launch_reduce(pl, pl->partial.d(), pl->sp_eddy.nsplit * (8 / pl->sp_eddy.dpw), (int64_t)2 * pl->K * pl->D,
+                       Bq2, st);
+}
+
+int temx_tracer_stage3(temx_plan* pl, const double* Bq2, double* tres, double* tzon, void* stream) {
+  int rc = tem_ready(pl);
+  if (rc) return rc;
+  if (!Bq2 || !tres) return fail(TEMX_EINVAL, "null argument");
+  if (!pl->tz.p) return fail(TEMX_ESTATE, "temx_tracer_stage2 has not been called");
+  HIPCHK(hipSetDevice(pl->device));
+  hipStream_t st = S_(stream);
+  const int64_t MD = (int64_t)pl->M * pl->D;
+  if ((rc = launch_solve(pl, Bq2, 2, pl->D, nullptr, pl->tz.d() + MD, st))) return rc;   // qpvpb, qpwappb
+  EpiTables tb{pl->p.d(), pl->pg.d(), pl->lg.d(), pl->coslat.d(), pl->fcor.d()};
+  hipLaunchKernelGGL(tracer_epilogue_kernel, dim3((unsigned)((MD + 255) / 256)), dim3(256), 0, st, pl->zb.d(),
+                     pl->tz.d(), pl->M, pl->nlev, pl->nt, tb, pl->p0, tres, tzon);
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+int temx_tracer_run(temx_plan* pl, const void* q, const void* va, const void* wap, int dtype,
+                    double* tres, double* tzon, void* stream) {
+  int rc = tem_ready(pl);
+  if (rc) return rc;
+  if ((rc = tracer_ws(pl))) return rc;
+  if ((rc = temx_tracer_stage1(pl, q, dtype, pl->Bq.d(), stream))) return rc;
+  if ((rc = temx_tracer_stage2(pl, q, va, wap, dtype, pl->Bq.d(), pl->Bq2.d(), stream))) return rc;
+  return temx_tracer_stage3(pl, pl->Bq2.d(), tres, tzon, stream);
+}
+
+int temx_tracer_eddy(temx_plan* pl, const void* q, const void* va, const void* wap, int dtype,
+                     double* const* ptrs3_host, void* stream) {
+  int rc = tem_ready(pl);
+  if (rc) return rc;
+  if (!q || !va || !wap || !ptrs3_host) return fail(TEMX_EINVAL, "null argument");
+  if (!pl->Ct.p) return fail(TEMX_ESTATE, "temx_tracer_stage2 has not been called");
+  HIPCHK(hipSetDevice(pl->device));
+  EddyOut eo{};
+  eo.p[0] = ptrs3_host[0];
+  eo.p[4] = ptrs3_host[1];
+  eo.p[5] = ptrs3_host[2];
+  return run_eddy<1>(pl, four(q, va, wap, nullptr), dtype, pl->Ct.d(), nullptr, &eo, S_(stream));
 }
 
 int temx_status(temx_plan* pl, int* nonfinite, void* stream) {

@@ -181,6 +181,59 @@ class Plan:
         check(self.lib.temx_tem_eddy(self._h, _ptr(u), _ptr(v), _ptr(t), _ptr(w), dt, ptrs, self._stream()))
         return outs
 
+    # ---- tracer TEM (one tracer at a time; needs a preceding tem_run on the same fields) ----
+    def _three(self, q, va, wap):
+        if self.D is None:
+            raise _lib.TemxError(-5, "temx_plan_set_tem has not been called")
+        fs = [self._field(x, self.D) for x in (q, va, wap)]
+        if len({f.dtype for f in fs}) != 1:
+            raise TypeError("q, va, wap must share one dtype")
+        return fs, _DT[fs[0].dtype]
+
+    def tracer_run(self, q, va, wap, want_zonal=False):
+        (qq, v, w), dt = self._three(q, va, wap)
+        tres = torch.empty((len(_lib.TRACER_RESULT_NAMES), self.M, self.nlev, self.nt), dtype=torch.float64,
+                           device=self.device)
+        tzon = None
+        if want_zonal:
+            tzon = torch.empty((len(_lib.TRACER_ZONAL_NAMES), self.M, self.nlev, self.nt), dtype=torch.float64,
+                               device=self.device)
+        check(self.lib.temx_tracer_run(self._h, _ptr(qq), _ptr(v), _ptr(w), dt, _ptr(tres),
+                                       _ptr(tzon) if tzon is not None else None, self._stream()))
+        return tres, tzon
+
+    def tracer_stage1(self, q):
+        qq = self._field(q, self.D)
+        Bq = torch.empty((self.K, self.D), dtype=torch.float64, device=self.device)
+        check(self.lib.temx_tracer_stage1(self._h, _ptr(qq), _DT[qq.dtype], _ptr(Bq), self._stream()))
+        return Bq
+
+    def tracer_stage2(self, q, va, wap, Bq):
+        (qq, v, w), dt = self._three(q, va, wap)
+        Bq2 = torch.empty((2, self.K, self.D), dtype=torch.float64, device=self.device)
+        check(self.lib.temx_tracer_stage2(self._h, _ptr(qq), _ptr(v), _ptr(w), dt, _ptr(Bq.contiguous()),
+                                          _ptr(Bq2), self._stream()))
+        return Bq2
+
+    def tracer_stage3(self, Bq2, want_zonal=False):
+        tres = torch.empty((len(_lib.TRACER_RESULT_NAMES), self.M, self.nlev, self.nt), dtype=torch.float64,
+                           device=self.device)
+        tzon = None
+        if want_zonal:
+            tzon = torch.empty((len(_lib.TRACER_ZONAL_NAMES), self.M, self.nlev, self.nt), dtype=torch.float64,
+                               device=self.device)
+        check(self.lib.temx_tracer_stage3(self._h, _ptr(Bq2.contiguous()), _ptr(tres),
+                                          _ptr(tzon) if tzon is not None else None, self._stream()))
+        return tres, tzon
+
+    def tracer_eddy(self, q, va, wap):
+        (qq, v, w), dt = self._three(q, va, wap)
+        outs = {n: torch.empty((self.N, self.nlev, self.nt), dtype=torch.float64, device=self.device)
+                for n in _lib.TRACER_EDDY_NAMES}
+        ptrs = (C.c_void_p * 3)(*[outs[n].data_ptr() for n in _lib.TRACER_EDDY_NAMES])
+        check(self.lib.temx_tracer_eddy(self._h, _ptr(qq), _ptr(v), _ptr(w), dt, ptrs, self._stream()))
+        return outs
+
     def status(self):
         """Synchronise; True when a non-finite value reached the zonal sums (NaN input)."""
         f = C.c_int(0)

@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["cubed_sphere_gll", "pressure_levels", "analytic_fields", "ncol_of_ne"]
+__all__ = ["cubed_sphere_gll", "pressure_levels", "analytic_fields", "analytic_tracer", "ncol_of_ne"]
 
 
 def ncol_of_ne(ne: int) -> int:
@@ -85,3 +85,18 @@ def analytic_fields(lat_deg, lon_deg, plev_hpa, nt, noise=0.1, seed=0, dtype=np.
         for a in (u, v, T, w):
             a += noise * rng.standard_normal(shape)
     return tuple(np.ascontiguousarray(a.astype(dtype)) for a in (u, v, T, w))
+
+
+def analytic_tracer(lat_deg, lon_deg, plev_hpa, nt, which=0, noise=0.02, seed=100, dtype=np.float64):
+    """A smooth positive mixing ratio ``[ncol][nlev][nt]`` (kg/kg-like magnitudes) for tracer TEM tests."""
+    phi = np.deg2rad(np.asarray(lat_deg, dtype=np.float64))[:, None, None]
+    lam = np.deg2rad(np.asarray(lon_deg, dtype=np.float64))[:, None, None]
+    p = np.asarray(plev_hpa, dtype=np.float64)[None, :, None]
+    t = np.arange(nt, dtype=np.float64)[None, None, :]
+    z = -7.0 * np.log(p / 1000.0)
+    q = (1e-3 * (1.0 + 0.5 * np.sin((which + 1) * phi)) * np.exp(-z / (7.0 + 3.0 * which))
+         * (1.0 + 0.1 * np.cos((2 + which) * lam + 0.1 * t) * np.cos(phi)))
+    if noise:
+        rng = np.random.default_rng(seed + which)
+        q = q * (1.0 + noise * rng.standard_normal(q.shape))
+    return np.ascontiguousarray(q.astype(dtype))

@@ -76,6 +76,17 @@ class TEMDiagnostics:
         self._eddy = None
         self._theta = None
         self._out_file = None
+        # ---- tracers (tem_diagnostics.py:532-538, 560-570, 602-611): one engine call each ----
+        self._tres, self._tzon, self._teddy = [], [], [None] * self.ntrac
+        self._last_tracer = None
+        for i in range(self.ntrac):
+            tres, tzon = plan.tracer_run(self._dev_q[i], self._dev_fields[1], self._dev_fields[3], want_zonal=True)
+            self._tres.append(tres)
+            self._tzon.append(tzon)
+            self._last_tracer = i
+        if self.ntrac and plan.status():
+            raise RuntimeError("Variable has nans! Spectral zonal averager cannot handle nans; "
+                               "please replace or remove them")
 
     # ------------------------------------------------------------------------------------------
     def _config_dims(self):
@@ -89,16 +100,21 @@ class TEMDiagnostics:
             self.timename = DEFAULT_DIMS["time"]
         self.data_dims = (self.ncolname, self.plevname, self.timename)
 
-        # tracers (tem_diagnostics.py:281-301): Abalos+ 2017 tracer TEM is the next scope row
+        # tracers (tem_diagnostics.py:281-301): a labelled array / raw array, or a list of them
         if self.q is not None:
-            ql = self.q if isinstance(self.q, list) else [self.q]
-            if not all(containers.is_labeled(x) for x in ql):
+            if not isinstance(self.q, list):
+                self.q = [self.q]
+            ok = all(containers.is_labeled(x) or isinstance(x, (np.ndarray, torch.Tensor)) for x in self.q)
+            if not ok or len(self.q) == 0:
                 raise RuntimeError("tracers q must be passed as an xarray DataArray, or"
                                    "a list of xarray DataArrays")
-            raise NotImplementedError("tracer TEM (q=...) is not part of this engine yet "
-                                      "(SURVEY.md section 8(f), row 1)")
-        self.ntrac = 0
-        self._q_out_file = []
+            self.ntrac = len(self.q)
+        else:
+            self.q = []
+            self.ntrac = 0
+        self._q_out_file = [None] * self.ntrac
+        for i, x in enumerate(self.q):
+            self._in["q{}".format(i)] = x
 
         lat = self.lat_native
         self._lat_native_np = np.asarray(lat.values if containers.is_labeled(lat) else
@@ -108,7 +124,7 @@ class TEMDiagnostics:
 
         labeled = [containers.is_labeled(v) for v in self._in.values()]
         if any(labeled) and not all(labeled):
-            raise RuntimeError("Input data for args ua, va, ta, wap must all be of the same kind")
+            raise RuntimeError("Input data for args ua, va, ta, wap (and q) must all be of the same kind")
         self._kind = "raw"
         if all(labeled):
             self._kind = "xarray" if containers.is_xarray(self._in["ua"]) else "labeled"
@@ -155,7 +171,7 @@ class TEMDiagnostics:
         self.NCOL, self.NLEV, self.NT = (int(s) for s in vals["ua"].shape)
         if plev.shape[0] != self.NLEV:
             raise RuntimeError("plev has {} entries but the data have {} levels".format(plev.shape[0], self.NLEV))
-        for var in ("va", "ta", "wap"):
+        for var in [v for v in vals if v != "ua"]:
             if tuple(vals[var].shape) != tuple(vals["ua"].shape):
                 raise RuntimeError("Input data {} has shape {}, expected {}".format(
                     var, tuple(vals[var].shape), tuple(vals["ua"].shape)))
@@ -193,16 +209,22 @@ class TEMDiagnostics:
             self._kind != "raw" and isinstance(self._in["ua"].values, torch.Tensor))
         self._dev_fields = [vals[k].to(device=dev, dtype=work).contiguous() for k in ("ua", "va", "ta", "wap")]
         self.ua, self.va, self.ta, self.wap = self._dev_fields
+        self._work_dtype = work
+        self._dev_q = [vals["q{}".format(i)].to(device=dev, dtype=work).contiguous() for i in range(self.ntrac)]
+        self._tracer_names = [getattr(x, "name", None) for x in self.q]
 
     # ------------------------------------------------------------------------------------------
     def _np_dtype(self, var):
         import torch
+        if isinstance(var, tuple):           # numpy promotion of a product of two inputs
+            return np.result_type(*[self._np_dtype(v) for v in var]).type
         return {torch.float32: np.float32, torch.float64: np.float64}.get(self._in_dtype[var], np.float64)
 
     def _wrap(self, t, name, src_var, native=False, force64=False):
         """Label a device result; cast like the reference's astype."""
         import torch
         dt = np.float64 if (force64 or name in _F64_ALWAYS) else self._np_dtype(src_var)
+        dt = np.float64 if dt == np.float64 else np.float32
         tdt = torch.float64 if dt == np.float64 else torch.float32
         t = t.to(tdt)
         vals = t if self._torch_out else t.cpu().numpy()
@@ -250,8 +272,32 @@ class TEMDiagnostics:
     int_vbdp = property(lambda s: s._zonal("int_vbdp", "va"))
     psi = property(lambda s: s._zonal("psi", "ta"))
     dpsi_dp = property(lambda s: s._zonal("dpsi_dp", "ta"))
-    # tracer getters exist for API parity; there are no tracers (ntrac == 0)
-    qp = qpvp = qpwapp = qb = qpvpb = qpwappb = dqb_dp = qbcoslat = dqbcoslat_dlat = property(lambda s: [])
+    # ---- tracer getters: lists, one entry per tracer (tem_diagnostics.py:458-475) ----
+    def _tzonal(self, name, src, force64=False):
+        k = _lib.TRACER_ZONAL_NAMES.index(name)
+        return [self._wrap(self._tzon[i][k], name, src(i), force64=force64) for i in range(self.ntrac)]
+
+    def _tnative(self, name, src):
+        out = []
+        for i in range(self.ntrac):
+            if self._teddy[i] is None:
+                plan = self.ZM._plan
+                if self._last_tracer != i:      # the plan holds the coefficients of one tracer at a time
+                    plan.tracer_run(self._dev_q[i], self._dev_fields[1], self._dev_fields[3])
+                    self._last_tracer = i
+                self._teddy[i] = plan.tracer_eddy(self._dev_q[i], self._dev_fields[1], self._dev_fields[3])
+            out.append(self._wrap(self._teddy[i][name], name, src(i), native=True))
+        return out
+
+    qb = property(lambda s: s._tzonal("qb", lambda i: "q%d" % i))
+    qpvpb = property(lambda s: s._tzonal("qpvpb", lambda i: ("q%d" % i, "va")))
+    qpwappb = property(lambda s: s._tzonal("qpwappb", lambda i: ("q%d" % i, "wap")))
+    dqb_dp = property(lambda s: s._tzonal("dqb_dp", lambda i: "q%d" % i))
+    qbcoslat = property(lambda s: s._tzonal("qbcoslat", lambda i: "q%d" % i, force64=True))
+    dqbcoslat_dlat = property(lambda s: s._tzonal("dqbcoslat_dlat", lambda i: "q%d" % i, force64=True))
+    qp = property(lambda s: s._tnative("qp", lambda i: "q%d" % i))
+    qpvp = property(lambda s: s._tnative("qpvp", lambda i: ("q%d" % i, "va")))
+    qpwapp = property(lambda s: s._tnative("qpwapp", lambda i: ("q%d" % i, "wap")))
 
     @property
     def theta(self):
@@ -272,7 +318,10 @@ class TEMDiagnostics:
 
     @property
     def q_out_file(self):
-        warnings.warn("'q_out_file' is emtpy; no tracers currently present")
+        if len(self._q_out_file) == 0:
+            warnings.warn("'q_out_file' is emtpy; no tracers currently present")
+        if self._q_out_file.count(None) == self.ntrac:
+            warnings.warn("'q_out_file' is not set until q_to_netcdf() is called")
         return self._q_out_file
 
     # ---- the ten diagnostics (tem_diagnostics.py:615-797), each cast to its input's dtype ----
@@ -287,9 +336,22 @@ class TEMDiagnostics:
     def utendvtem(self): return self._result("utendvtem", "ua")        # noqa: E704
     def utendwtem(self): return self._result("utendwtem", "ua")        # noqa: E704
 
-    def _no_tracers(self, *a, **k):
-        raise RuntimeError("no tracers present (argument `q` not passed at object construction)")
-    etfy = etfz = etdiv = qtendetfd = qtendvtem = qtendwtem = _no_tracers
+    # ---- tracer TEM (Abalos+ 2017), tem_diagnostics.py:801-991 ----
+    def _tracer_result(self, name, qi):
+        if qi is None and self.ntrac == 1:
+            qi = 0
+        elif qi is None and self.ntrac > 1:                                   # :815-816 ...
+            raise RuntimeError("qi must be passed to {}() when len(q) > 1!".format(name))
+        if self.ntrac == 0:
+            raise RuntimeError("no tracers present (argument `q` not passed at object construction)")
+        return self._wrap(self._tres[qi][_lib.TRACER_RESULT_NAMES.index(name)], name, "q%d" % qi)
+
+    def etfy(self, qi=None): return self._tracer_result("etfy", qi)               # noqa: E704
+    def etfz(self, qi=None): return self._tracer_result("etfz", qi)               # noqa: E704
+    def etdiv(self, qi=None): return self._tracer_result("etdiv", qi)             # noqa: E704
+    def qtendetfd(self, qi=None): return self._tracer_result("qtendetfd", qi)     # noqa: E704
+    def qtendvtem(self, qi=None): return self._tracer_result("qtendvtem", qi)     # noqa: E704
+    def qtendwtem(self, qi=None): return self._tracer_result("qtendwtem", qi)     # noqa: E704
 
     def results(self):
         return {n: getattr(self, n)() for n in _lib.RESULT_NAMES}
@@ -326,5 +388,24 @@ class TEMDiagnostics:
         dims = x.dims if containers.is_labeled(x) else ("lat", self.plevname, self.timename)
         return xr.DataArray(v, dims=dims)
 
-    def q_to_netcdf(self, *a, **k):
+    def q_to_netcdf(self, loc=os.getcwd(), qi=None, prefix=None, include_attrs=False):
+        """tem_diagnostics.py:1045-1103 (file naming and variable set; needs xarray + NetCDF)."""
         assert self.ntrac > 0, "No tracers to output (argument `q` not passed at object construction)"
+        prefix = "{}_".format(prefix) if prefix is not None else ""
+        names = [n if n is not None else "q{}".format(i) for i, n in enumerate(self._tracer_names)]
+        idx = range(self.ntrac) if qi is None else [qi]
+        try:
+            import xarray as xr
+        except ImportError as e:
+            raise RuntimeError("q_to_netcdf() needs xarray and a NetCDF back end, which are not installed") from e
+        for i in idx:
+            out = {n: self._as_xr(getattr(self, n)(i)) for n in _lib.TRACER_RESULT_NAMES}
+            if include_attrs:   # (sic) key 'dqp_dp' as in tem_diagnostics.py:1081
+                attrs = {"qpvp": self.qpvp[i], "qpwapp": self.qpwapp[i], "qpvpb": self.qpvpb[i],
+                         "qpwappb": self.qpwappb[i], "dqp_dp": self.dqb_dp[i], "qbcoslat": self.qbcoslat[i],
+                         "dqbcoslat_dlat": self.dqbcoslat_dlat[i]}
+                out = dict({k: self._as_xr(v) for k, v in attrs.items()}, **out)
+            self._q_out_file[i] = "{}/{}TEM_{}_{}_L{}_TRACER-{}.nc".format(
+                loc, prefix, self.ZM.grid_name, self.ZM.grid_out_name, self.L, names[i])
+            xr.Dataset(out).to_netcdf(self._q_out_file[i])
+        return self._q_out_file

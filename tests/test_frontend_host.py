@@ -62,9 +62,9 @@ def test_frontend_validation_errors_match_reference():
     with pytest.raises(RuntimeError, match="xarray DataArray"):                # :313
         TEMDiagnostics([1, 2], [1, 2], [1, 2], [1, 2], lat, plev=plev, debug_level=0)
     with pytest.raises(RuntimeError, match="tracers"):                          # :294
-        TEMDiagnostics(good, good, good, good, lat, q=[np.ones(3)], debug_level=0)
-    with pytest.raises(NotImplementedError):
-        TEMDiagnostics(good, good, good, good, lat, q=good, debug_level=0)
+        TEMDiagnostics(good, good, good, good, lat, q=["not an array"], debug_level=0)
+    with pytest.raises(RuntimeError, match="same kind"):
+        TEMDiagnostics(good, good, good, good, lat, q=[np.ones((N, nlev, nt))], debug_level=0)
 
 
 def test_averager_constructor_attributes_without_gpu():

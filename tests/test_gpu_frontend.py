@@ -123,3 +123,62 @@ def test_tem_nan_input_raises():
     ta = g["ta"].copy(); ta[100, 2, 1] = np.nan
     with pytest.raises(RuntimeError, match="nans"):
         TEMDiagnostics(g["ua"], g["va"], ta, g["wap"], g["lat"], plev=g["plev"], L=20, zm_dlat=3, debug_level=0)
+
+
+TRES = ("etfy", "etfz", "etdiv", "qtendetfd", "qtendvtem", "qtendwtem")
+TZON = ("qb", "qpvpb", "qpwappb", "dqb_dp", "qbcoslat", "dqbcoslat_dlat")
+TNAT = ("qp", "qpvp", "qpwapp")
+
+
+@pytest.mark.parametrize("case", ["tracer_ne4_10x2_f64", "tracer_ne4_10x2_qf32"])
+def test_tracer_tem_matches_reference(case):
+    """Abalos+ 2017 tracer TEM (tem_diagnostics.py:532-538, 560-570, 602-611, 801-991)."""
+    from pytemdiags_amd import TEMDiagnostics, LabeledArray
+    g = load(case)
+    nq = int(g["ntrac"])
+    f32 = g["q0"].dtype == np.float32
+    tol = 2e-5 if f32 else 1e-10
+    q = [LabeledArray(g["q%d" % i], ("ncol", "plev", "time"), {"plev": g["plev"], "time": g["time"]},
+                      name="Q%d" % i) for i in range(nq)]
+    tem = TEMDiagnostics(labeled(g, "ua"), labeled(g, "va"), labeled(g, "ta"), labeled(g, "wap"),
+                         LabeledArray(g["lat"], ("ncol",)), q=q if nq > 1 else q[0], debug_level=0)
+    assert tem.ntrac == nq
+    for n in RESULTS:
+        assert fieldnorm_err(getattr(tem, n)().values, g["res_" + n]) <= (1e-10 if not f32 else 1e-10), n
+    if nq > 1:
+        with pytest.raises(RuntimeError, match="qi must be passed"):      # tem_diagnostics.py:815
+            tem.etfy()
+    else:
+        assert fieldnorm_err(tem.etfy().values, g["q0_res_etfy"]) <= tol
+    for i in range(nq):
+        for n in TRES:
+            r = getattr(tem, n)(i)
+            ref = g["q%d_res_%s" % (i, n)]
+            assert r.dims == ("lat", "plev", "time") and r.dtype == ref.dtype, n
+            assert fieldnorm_err(r.values, ref) <= tol, (i, n, fieldnorm_err(r.values, ref))
+        for n in TZON:
+            z = getattr(tem, n)[i]
+            ref = g["q%d_%s" % (i, n)]
+            assert z.dtype == ref.dtype, (n, z.dtype, ref.dtype)
+            assert fieldnorm_err(z.values, ref) <= tol, (i, n)
+        for n in TNAT:
+            e = getattr(tem, n)[i]
+            ref = g["q%d_%s" % (i, n)]
+            assert e.dims == ("ncol", "plev", "time") and e.dtype == ref.dtype, (n, e.dtype, ref.dtype)
+            assert fieldnorm_err(e.values, ref) <= tol, (i, n)
+
+
+def test_tracer_staged_equals_fused():
+    from pytemdiags_amd import engine
+    g = load("tracer_ne4_10x2_f64")
+    lat_zm = (np.arange(-90, 91, 1.0)[1:] + np.arange(-90, 91, 1.0)[:-1]) / 2
+    plan = engine.Plan(g["lat"], lat_zm, 50)
+    plan.set_tem(10, 2, g["plev"] * 100)
+    d = {k: torch.as_tensor(g[k], device="cuda:0") for k in ("ua", "va", "ta", "wap", "q0", "q1")}
+    plan.tem_run(d["ua"], d["va"], d["ta"], d["wap"])
+    t1, _ = plan.tracer_run(d["q1"], d["va"], d["wap"])
+    Bq = plan.tracer_stage1(d["q1"])
+    Bq2 = plan.tracer_stage2(d["q1"], d["va"], d["wap"], Bq)
+    t2, _ = plan.tracer_stage3(Bq2)
+    assert torch.equal(t1, t2) and not plan.status()
+    plan.close()

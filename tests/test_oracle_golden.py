@@ -98,3 +98,27 @@ def test_nan_and_shape_errors():
         Z.zonal_mean(A)
     with pytest.raises(RuntimeError):
         Z.zonal_mean(np.zeros(7))
+
+
+@pytest.mark.parametrize("case", ["tracer_ne4_10x2_f64", "tracer_ne4_10x2_qf32"])
+@pytest.mark.parametrize("mode", ["literal", "factorised"])
+def test_tracer_oracle_matches_reference_goldens(case, mode):
+    """Tracer TEM (Abalos+ 2017): tem_diagnostics.py:532-538, 560-570, 602-611, 801-991."""
+    g = load(case)
+    nq = int(g["ntrac"])
+    q = [g["q%d" % i] for i in range(nq)]
+    o = orc.TEMOracle(g["ua"], g["va"], g["ta"], g["wap"], g["lat"], g["plev"], mode=mode, q=q)
+    f32 = q[0].dtype == np.float32
+    tol = {("literal", False): 1e-12, ("factorised", False): 1e-10,
+           ("literal", True): 2e-6, ("factorised", True): 2e-5}[(mode, f32)]
+    for n in orc.RESULTS:
+        assert fieldnorm_err(getattr(o, n)(), g["res_" + n]) <= tol
+    for i in range(nq):
+        for n in orc.TRACER_RESULTS:
+            r = getattr(o, n)(i)
+            assert r.dtype == g["q%d_res_%s" % (i, n)].dtype, n
+            assert fieldnorm_err(r, g["q%d_res_%s" % (i, n)]) <= tol, (i, n)
+        for n in orc.TRACER_ZONAL + orc.TRACER_NATIVE:
+            x = getattr(o, n)[i]
+            assert x.dtype == g["q%d_%s" % (i, n)].dtype, n
+            assert fieldnorm_err(x, g["q%d_%s" % (i, n)]) <= tol, (i, n)

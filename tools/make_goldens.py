@@ -103,6 +103,36 @@ def operator_case(name, ne, L):
     print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6))
 
 
+def tracer_case(name, ne, nlev, nt, qdtypes=(np.float64, np.float64), dtype=np.float64, seed=2):
+    """TEM with tracers (tem_diagnostics.py:281-301, 532-538, 560-570, 602-611, 801-991)."""
+    TRES = ("etfy", "etfz", "etdiv", "qtendetfd", "qtendvtem", "qtendwtem")
+    TZON = ("qb", "qpvpb", "qpwappb", "dqb_dp", "qbcoslat", "dqbcoslat_dlat")
+    TNAT = ("qp", "qpvp", "qpwapp")
+    lat, lon = synth.cubed_sphere_gll(ne)
+    plev = synth.pressure_levels(nlev)
+    time = 6.0 * np.arange(nt)
+    ua, va, ta, wap = synth.analytic_fields(lat, lon, plev, nt, noise=0.1, seed=seed, dtype=dtype)
+    qs = [synth.analytic_tracer(lat, lon, plev, nt, which=i, dtype=dt) for i, dt in enumerate(qdtypes)]
+    qarg = [da(x, plev, time) for x in qs]
+    tem = PyTEMDiags.TEMDiagnostics(
+        da(ua, plev, time), da(va, plev, time), da(ta, plev, time), da(wap, plev, time),
+        xr.DataArray(lat, dims=("ncol",)), q=qarg if len(qarg) > 1 else qarg[0], debug_level=0,
+        map_save_dest="/nonexistent")
+    out = dict(lat=lat, lon=lon, plev=plev, time=time, ua=ua, va=va, ta=ta, wap=wap, ntrac=np.int64(len(qs)))
+    for n in RESULTS:
+        out["res_" + n] = getattr(tem, n)().values
+    for i, x in enumerate(qs):
+        out["q%d" % i] = x
+        for n in TRES:
+            out["q%d_res_%s" % (i, n)] = getattr(tem, n)(i).values
+        for n in TZON + TNAT:
+            out["q%d_%s" % (i, n)] = getattr(tem, n)[i].values
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6),
+          {n: float(np.max(np.abs(out["q0_res_" + n]))) for n in TRES})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     tem_case("tem_ne4_30x1_f64", 4, 30, 1)                                   # BASELINE config 1
@@ -111,3 +141,5 @@ if __name__ == "__main__":
     tem_case("tem_ne4_12x3_L20_dlat3", 4, 12, 3, L=20, zm_dlat=3, keep_native=False, seed=5)
     tem_case("tem_ne8_20x2_f64", 8, 20, 2, keep_native=False, seed=1)
     operator_case("op_ne4_L30", 4, 30)
+    tracer_case("tracer_ne4_10x2_f64", 4, 10, 2)
+    tracer_case("tracer_ne4_10x2_qf32", 4, 10, 2, qdtypes=(np.float32,))
