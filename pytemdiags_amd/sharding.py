@@ -65,6 +65,16 @@ class NcolShardedTEM:
         allreduce_sum_(B3, self.group)                 # (iii) [3][K][D] flux sums, one message
         return be.tem_stage3(B3, want_zonal)
 
+    def run_tracer(self, q, va, wap, want_zonal=False):
+        """Tracer TEM for one tracer; call after ``run`` on the same fields (two more all-reduces:
+        [K][D] sums of q, [2][K][D] sums of q'v', q'w')."""
+        be = self.backend
+        Bq = be.tracer_stage1(q)
+        allreduce_sum_(Bq, self.group)
+        Bq2 = be.tracer_stage2(q, va, wap, Bq)
+        allreduce_sum_(Bq2, self.group)
+        return be.tracer_stage3(Bq2, want_zonal)
+
 
 class TimeShardedTEM:
     """Replicated plan, private time block per rank; outputs stay sharded along time."""

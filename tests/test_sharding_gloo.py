@@ -54,6 +54,7 @@ class OracleBackend:
         C = [self.Ginv @ b for b in B4.numpy()]
         self.zon = {n: (self.Y0p @ c).reshape((-1,) + tr) for n, c in zip(("ub", "vb", "thetab", "wapb"), C)}
         e = [x - self.Y0 @ c for x, c in zip(X, C)]
+        self.e = e
         prods = [e[0] * e[1], e[0] * e[3], e[1] * e[2]]
         self.tr = tr
         return torch.from_numpy(np.stack([self.Y0.T @ p for p in prods]))
@@ -65,9 +66,31 @@ class OracleBackend:
         res = torch.from_numpy(np.stack([getattr(o, n)() for n in orc.RESULTS]))
         return res, None
 
+    def tracer_stage1(self, q):
+        self.qf = np.asarray(q).reshape(q.shape[0], -1)
+        return torch.from_numpy(self.Y0.T @ self.qf)
+
+    def tracer_stage2(self, q, va, wap, Bq):
+        cq = self.Ginv @ Bq.numpy()
+        self.zon_q = {"qb": (self.Y0p @ cq).reshape((-1,) + self.tr)}
+        qp = self.qf - self.Y0 @ cq
+        return torch.from_numpy(np.stack([self.Y0.T @ (qp * self.e[1]), self.Y0.T @ (qp * self.e[3])]))
+
+    def tracer_stage3(self, Bq2, want_zonal=False):
+        for n, b in zip(("qpvpb", "qpwappb"), Bq2.numpy()):
+            self.zon_q[n] = (self.Y0p @ (self.Ginv @ b)).reshape((-1,) + self.tr)
+        o = orc.TEMOracle.from_zonal_means(self.zon, self.plev)
+        o.q = [np.empty(0)]
+        o.qb, o.qpvpb, o.qpwappb = [self.zon_q["qb"]], [self.zon_q["qpvpb"]], [self.zon_q["qpwappb"]]
+        o._derivatives()
+        return torch.from_numpy(np.stack([getattr(o, n)(0) for n in orc.TRACER_RESULTS])), None
+
     def tem_run(self, ua, va, ta, wap, want_zonal=False):
         B4 = self.tem_stage1(ua, va, ta, wap)
         return self.tem_stage3(self.tem_stage2(ua, va, ta, wap, B4), want_zonal)
+
+
+_LON = synth.cubed_sphere_gll(NE)[1]
 
 
 def _data():
@@ -89,6 +112,9 @@ def _worker(rank, world, port, mode, ret):
             be = OracleBackend(lat[i0:i1], lat_zm, L, plev)
             runner = sharding.NcolShardedTEM(be)
             res, _ = runner.run(*[x[i0:i1] for x in f])
+            q = synth.analytic_tracer(lat, _LON, plev, NT)
+            tres, _ = runner.run_tracer(q[i0:i1], f[1][i0:i1], f[3][i0:i1])
+            res = torch.cat([res, tres])
         else:
             be = OracleBackend(lat, lat_zm, L, plev)
             be.finalize((be.Y0.T @ be.Y0))
@@ -113,7 +139,8 @@ def _free_port():
 @pytest.mark.parametrize("mode", ["ncol", "time"])
 def test_sharded_pipeline_world2_gloo(mode):
     lat, plev, f = _data()
-    ref = orc.TEMOracle(*f, lat, plev, L=L, mode="factorised")
+    q = synth.analytic_tracer(lat, _LON, plev, NT)
+    ref = orc.TEMOracle(*f, lat, plev, L=L, mode="factorised", q=q)
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = _free_port()
@@ -124,11 +151,16 @@ def test_sharded_pipeline_world2_gloo(mode):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert got.shape == (10, 180, NLEV, NT)
+    assert got.shape == ((16 if mode == "ncol" else 10), 180, NLEV, NT)
     for i, n in enumerate(orc.RESULTS):
         r = getattr(ref, n)()
         err = np.max(np.abs(got[i] - r)) / np.max(np.abs(r))
         assert err <= 1e-10, (mode, n, err)
+    if mode == "ncol":      # tracer TEM through the sharded driver (two more all-reduces)
+        for i, n in enumerate(orc.TRACER_RESULTS):
+            r = getattr(ref, n)(0)
+            err = np.max(np.abs(got[10 + i] - r)) / np.max(np.abs(r))
+            assert err <= 1e-10, (mode, n, err)
 
 
 def test_world1_is_a_no_op():
