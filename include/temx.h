@@ -43,7 +43,10 @@ enum {
   TEMX_EUNSUPPORTED = -6
 };
 
-enum { TEMX_DEFER_FINALIZE = 1 };
+enum {
+  TEMX_DEFER_FINALIZE = 1,
+  TEMX_NO_SYMMETRY = 2   /* do not use the mirror-paired sweeps even if the grid is equatorially symmetric */
+};
 
 /* which matrix temx_get_matrix copies */
 enum {
@@ -83,7 +86,10 @@ int temx_device_count(void);
  * device by the normalised Legendre recurrence, the Gram matrix G = Y0^T Y0 with the MFMA
  * projection kernel, and (unless TEMX_DEFER_FINALIZE) factorises G on the host (Cholesky),
  * which replaces lstsq(Y0, I_N) (sph_zonal_mean.py:389): pinv(Y0) = G^-1 Y0^T.
- * lat_deg_host[ncol], lat_out_deg_host[M] in degrees.  L <= 63 in this version. */
+ * lat_deg_host[ncol], lat_out_deg_host[M] in degrees.  L <= 63 in this version.
+ * If every column has a mirror column at the opposite latitude (cubed-sphere, lat-lon, Gaussian
+ * grids) the TEM sweeps run in a mirror-paired form that needs ~54 % of the matrix work (same
+ * operator, results equal up to rounding); flags & TEMX_NO_SYMMETRY or TEMX_NO_SYM=1 disables it. */
 int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
                      const double* lat_deg_host, const double* lat_out_deg_host, int flags);
 

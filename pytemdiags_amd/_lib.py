@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libtemx.so")
 
 F64, F32 = 0, 1
 DEFER_FINALIZE = 1
+NO_SYMMETRY = 2
 MAT_Y0, MAT_Y0P, MAT_GRAM, MAT_GINV, MAT_Y0INV = 0, 1, 2, 3, 4
 
 RESULT_NAMES = ("vtem", "omegatem", "wtem", "psitem", "epfy", "epfz", "epdiv",

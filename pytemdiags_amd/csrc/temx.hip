@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "kernels_sym.hpp"
 
 using namespace temx;
 
@@ -92,6 +93,12 @@ struct temx_plan {
   DevBuf B4, B3, C4, zb;
   DevBuf Bq, Bq2, Ct, tz;          // tracer workspace: sums, coefficients (q, v, w), zonal means
   Split sp_proj1, sp_eddy_t;
+  // mirror-paired path (equatorially symmetric grids), see kernels_sym.hpp
+  bool sym = false;
+  int TBS = 0;
+  int64_t npair = 0, npg = 0, npg_alloc = 0;
+  DevBuf rows, ysym;
+  Split sp_sproj4, sp_sproj1, sp_seddy;
   Split sp_proj4, sp_eddy;
   // shared workspaces
   DevBuf partial;
@@ -317,6 +324,106 @@ static int launch_recon(temx_plan* pl, int64_t D, const double* C, double* out, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// mirror pairing of an equatorially symmetric grid (kernels_sym.hpp)
+// ------------------------------------------------------------------------------------------------
+// Every column with lat > tol must have a partner with the opposite latitude (any longitude);
+// |lat| <= tol are equator columns (pairs without a southern partner).  Returns false if the grid is
+// not symmetric.  Pairs are ordered by their northern row so one operand still streams.
+static bool find_mirror_pairs(const double* lat, int64_t N, std::vector<int>& rowN, std::vector<int>& rowS) {
+  if (N >= ((int64_t)1 << 31)) return false;
+  const double tol = 1e-12;   // degrees
+  std::vector<int> north, south, eq;
+  for (int64_t i = 0; i < N; ++i) {
+    if (!(std::fabs(lat[i]) <= 90.0 + 1e-9)) return false;
+    if (lat[i] > tol) north.push_back((int)i);
+    else if (lat[i] < -tol) south.push_back((int)i);
+    else eq.push_back((int)i);
+  }
+  if (north.size() != south.size()) return false;
+  std::stable_sort(north.begin(), north.end(), [&](int a, int b) { return lat[a] < lat[b]; });
+  std::stable_sort(south.begin(), south.end(), [&](int a, int b) { return -lat[a] < -lat[b]; });
+  std::vector<std::pair<int, int>> pairs;
+  pairs.reserve(north.size() + eq.size());
+  for (size_t k = 0; k < north.size(); ++k) {
+    if (std::fabs(lat[north[k]] + lat[south[k]]) > tol) return false;
+    pairs.emplace_back(north[k], south[k]);
+  }
+  for (int e : eq) pairs.emplace_back(e, -1);
+  std::sort(pairs.begin(), pairs.end());
+  rowN.resize(pairs.size());
+  rowS.resize(pairs.size());
+  for (size_t k = 0; k < pairs.size(); ++k) {
+    rowN[k] = pairs[k].first;
+    rowS[k] = pairs[k].second;
+  }
+  return true;
+}
+
+template <typename T, int NF>
+static int launch_project_sym_t(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t D, const double* colscale,
+                                int sfield, double* partial, const Split& sp, hipStream_t st) {
+  dim3 grid(sp.grid), block(256);
+#define TEMX_LPS(TBSv)                                                                              \
+  hipLaunchKernelGGL((project_sym_kernel<T, NF, TBSv>), grid, block, 0, st, fp, D, pl->K,           \
+                     pl->ysym.d(), static_cast<const int*>(pl->rows.p), pl->npg, colscale, sfield,  \
+                     partial, sp.nsplit, sp.ndt)
+  switch (pl->TBS) {
+    case 2: TEMX_LPS(2); break;
+    case 4: TEMX_LPS(4); break;
+    case 7: TEMX_LPS(7); break;
+    default: TEMX_LPS(8); break;
+  }
+#undef TEMX_LPS
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+template <int NF>
+static int launch_project_sym(temx_plan* pl, const FieldPtrs<NF>& fp, int dtype, int64_t D,
+                              const double* colscale, int sfield, double* partial, const Split& sp,
+                              hipStream_t st) {
+  if (dtype == TEMX_F64) return launch_project_sym_t<double, NF>(pl, fp, D, colscale, sfield, partial, sp, st);
+  if (dtype == TEMX_F32) return launch_project_sym_t<float, NF>(pl, fp, D, colscale, sfield, partial, sp, st);
+  return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
+}
+
+template <typename T, int MODE, int DPW, int KIND>
+static int launch_eddy_sym_d(temx_plan* pl, const FieldPtrs<4>& fp, const double* C, double* partial,
+                             const Split& sp, const EddyOut& eo, hipStream_t st) {
+  dim3 grid(sp.grid), block(512);
+  constexpr int NFR = KIND == 0 ? 4 : 3;
+#define TEMX_LES(TBSv)                                                                                \
+  do {                                                                                                \
+    auto kern = eddy_sym_kernel<T, TBSv, MODE, DPW, KIND>;                                            \
+    const size_t lds = ((size_t)DPW * NFR * 2 * TBSv * 64 + 8 * 2 * TBSv * 16) * sizeof(double);      \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->D, pl->K, pl->K4, pl->ysym.d(),            \
+                       static_cast<const int*>(pl->rows.p), pl->npg, pl->npair, pl->colscale.d(), C,  \
+                       partial, sp.nsplit, sp.ndt, eo);                                               \
+  } while (0)
+  switch (pl->TBS) {
+    case 2: TEMX_LES(2); break;
+    case 4: TEMX_LES(4); break;
+    case 7: TEMX_LES(7); break;
+    default: TEMX_LES(8); break;
+  }
+#undef TEMX_LES
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+template <typename T, int MODE, int KIND>
+static int launch_eddy_sym_t(temx_plan* pl, const FieldPtrs<4>& fp, const double* C, double* partial,
+                             const Split& sp, const EddyOut& eo, hipStream_t st) {
+  switch (sp.dpw) {
+    case 1: return launch_eddy_sym_d<T, MODE, 1, KIND>(pl, fp, C, partial, sp, eo, st);
+    case 2: return launch_eddy_sym_d<T, MODE, 2, KIND>(pl, fp, C, partial, sp, eo, st);
+    default: return launch_eddy_sym_d<T, MODE, 4, KIND>(pl, fp, C, partial, sp, eo, st);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host linear algebra: Cholesky inverse of the K x K Gram matrix (K <= 64)
 // ------------------------------------------------------------------------------------------------
 static int spd_inverse(const double* G, int K, double* Ginv) {
@@ -379,11 +486,25 @@ static void gradient_table(const std::vector<double>& x, std::vector<double>& ta
 }
 
 static inline hipStream_t S_(void* s) { return static_cast<hipStream_t>(s); }
+static inline const Split& eddy_split(const temx_plan* pl) { return pl->sym ? pl->sp_seddy : pl->sp_eddy; }
+static inline int eddy_slabs(const temx_plan* pl) { return eddy_split(pl).nsplit * (8 / eddy_split(pl).dpw); }
+static inline bool sym_project(const temx_plan* pl, int nf) {   // paired project sweep needs d-quads
+  return pl->sym && (nf == 4 ? pl->sp_sproj4.nsplit : pl->sp_sproj1.nsplit) > 0;
+}
 
 template <int KIND>
 static int run_eddy(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, const double* C, double* partial,
                     const EddyOut* eo, hipStream_t st) {
   EddyOut none{};
+  if (pl->sym) {
+    if (dtype == TEMX_F64)
+      return eo ? launch_eddy_sym_t<double, 1, KIND>(pl, fp, C, partial, pl->sp_seddy, *eo, st)
+                : launch_eddy_sym_t<double, 0, KIND>(pl, fp, C, partial, pl->sp_seddy, none, st);
+    if (dtype == TEMX_F32)
+      return eo ? launch_eddy_sym_t<float, 1, KIND>(pl, fp, C, partial, pl->sp_seddy, *eo, st)
+                : launch_eddy_sym_t<float, 0, KIND>(pl, fp, C, partial, pl->sp_seddy, none, st);
+    return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
+  }
   if (dtype == TEMX_F64) {
     return eo ? launch_eddy_t<double, 1, KIND>(pl, fp, C, partial, pl->sp_eddy, *eo, st)
               : launch_eddy_t<double, 0, KIND>(pl, fp, C, partial, pl->sp_eddy, none, st);
@@ -422,7 +543,7 @@ void temx_plan_destroy(temx_plan* pl) {
   DevBuf* bufs[] = {&pl->x, &pl->Y0, &pl->yblk, &pl->yblk_w, &pl->Y0p, &pl->G, &pl->Ginv, &pl->norm,
                     &pl->flag, &pl->p, &pl->pg, &pl->lg, &pl->coslat, &pl->fcor, &pl->colscale,
                     &pl->B4, &pl->B3, &pl->C4, &pl->zb, &pl->partial, &pl->opB, &pl->opC,
-                    &pl->Bq, &pl->Bq2, &pl->Ct, &pl->tz};
+                    &pl->Bq, &pl->Bq2, &pl->Ct, &pl->tz, &pl->rows, &pl->ysym};
   for (DevBuf* b : bufs) b->release();
   for (int w = 0; w < 2; ++w)
     for (auto& tl : pl->timed[w]) {
@@ -520,6 +641,34 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
     if ((rc = launch_reduce(pl, pl->partial.d(), sp.nsplit, (int64_t)pl->K * pl->K, pl->G.d(), 0))) return bail(rc);
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return bail(fail(TEMX_EHIP, "gram kernel failed: %s", hipGetErrorString(e)));
+  }
+  // mirror pairing (kernels_sym.hpp): ~46 % fewer MFMAs on equatorially symmetric grids
+  {
+    const char* e = getenv("TEMX_NO_SYM");
+    std::vector<int> rN, rS;
+    if (!(flags & TEMX_NO_SYMMETRY) && !(e && e[0] == '1') && find_mirror_pairs(lat_deg_host, ncol, rN, rS)) {
+      const int nhalf = (pl->K + 1) / 2;                       // even harmonics (>= odd ones)
+      const int tbs = (nhalf + 3) / 4;
+      pl->TBS = tbs <= 2 ? 2 : (tbs <= 4 ? 4 : (tbs <= 7 ? 7 : 8));
+      pl->npair = (int64_t)rN.size();
+      pl->npg = (pl->npair + 3) / 4;
+      pl->npg_alloc = ((pl->npg + 1) / 2 + 1) * 2;             // whole chunks of 2 groups + 1 chunk
+      const int64_t n4 = pl->npg_alloc * 4;
+      std::vector<int> rows((size_t)2 * n4, 0);
+      for (int64_t k = 0; k < n4; ++k) rows[(size_t)n4 + k] = -1;
+      for (int64_t k = 0; k < pl->npair; ++k) {
+        rows[(size_t)k] = rN[(size_t)k];
+        rows[(size_t)n4 + k] = rS[(size_t)k];
+      }
+      if ((rc = upload(pl->rows, rows.data(), rows.size() * sizeof(int)))) return bail(rc);
+      if ((rc = pl->ysym.ensure((size_t)pl->npg_alloc * 2 * pl->TBS * 16 * 8))) return bail(rc);
+      hipLaunchKernelGGL(sym_basis_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, 0, pl->x.d(),
+                         static_cast<const int*>(pl->rows.p), pl->npair, n4, pl->K, pl->TBS, pl->norm.d(),
+                         pl->ysym.d());
+      hipError_t e2 = hipDeviceSynchronize();
+      if (e2 != hipSuccess) return bail(fail(TEMX_EHIP, "sym basis kernel failed: %s", hipGetErrorString(e2)));
+      pl->sym = true;
+    }
   }
   if (!(flags & TEMX_DEFER_FINALIZE)) {
     if ((rc = temx_plan_finalize(pl, nullptr))) return bail(rc);
@@ -702,6 +851,19 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
   if ((rc = pl->C4.ensure((size_t)4 * pl->K4 * D * 8))) return rc;
   if ((rc = pl->zb.ensure((size_t)8 * M * D * 8))) return rc;
   pl->sp_proj1 = choose_split(D, pl->nchunk, 2 * pl->num_cu);
+  if (pl->sym) {
+    const int64_t nch = (pl->npg + 1) / 2;
+    pl->sp_sproj4 = Split();
+    pl->sp_sproj1 = Split();
+    if (pick_dpw(ndt_, 4) == 4) {     // the paired project sweep is built for quads of d-tiles
+      pl->sp_sproj4 = choose_split(D, nch, 2 * pl->num_cu, 4);
+      pl->sp_sproj1 = choose_split(D, nch, 2 * pl->num_cu, 4);
+    }
+    pl->sp_seddy = choose_split(D, pl->npg / (8 / edpw), pl->num_cu, edpw);
+    const size_t need2 = (size_t)std::max({pl->sp_sproj4.nsplit * 4, pl->sp_seddy.nsplit * (8 / edpw) * 3,
+                                           pl->sp_sproj1.nsplit}) * pl->K * D * 8;
+    if ((rc = pl->partial.ensure(std::max(need2, pl->partial.bytes)))) return rc;
+  }
   pl->tem = true;
   return TEMX_OK;
 }
@@ -724,10 +886,13 @@ int temx_tem_stage1(temx_plan* pl, const void* ua, const void* va, const void* t
   fp.p[0] = ua; fp.p[1] = va; fp.p[2] = ta; fp.p[3] = wap;
   TimedLaunch tl{};
   time_begin(pl, 0, st, tl);
-  rc = launch_project<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->partial.d(), pl->sp_proj4, st);
+  const bool sp4 = sym_project(pl, 4);
+  rc = sp4 ? launch_project_sym<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->partial.d(), pl->sp_sproj4, st)
+           : launch_project<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->partial.d(), pl->sp_proj4, st);
   time_end(pl, 0, st, tl);
   if (rc) return rc;
-  return launch_reduce(pl, pl->partial.d(), pl->sp_proj4.nsplit, (int64_t)4 * pl->K * pl->D, B4, st);
+  return launch_reduce(pl, pl->partial.d(), sp4 ? pl->sp_sproj4.nsplit : pl->sp_proj4.nsplit,
+                       (int64_t)4 * pl->K * pl->D, B4, st);
 }
 
 int temx_tem_stage2(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap,
@@ -744,8 +909,7 @@ int temx_tem_stage2(temx_plan* pl, const void* ua, const void* va, const void* t
   rc = run_eddy<0>(pl, four(ua, va, ta, wap), dtype, pl->C4.d(), pl->partial.d(), nullptr, st);
   time_end(pl, 1, st, tl);
   if (rc) return rc;
-  return launch_reduce(pl, pl->partial.d(), pl->sp_eddy.nsplit * (8 / pl->sp_eddy.dpw), (int64_t)3 * pl->K * pl->D, B3,
-                       st);
+  return launch_reduce(pl, pl->partial.d(), eddy_slabs(pl), (int64_t)3 * pl->K * pl->D, B3, st);
 }
 
 int temx_tem_stage3(temx_plan* pl, const double* B3, double* results, double* zonal, void* stream) {
@@ -809,8 +973,12 @@ int temx_tracer_stage1(temx_plan* pl, const void* q, int dtype, double* Bq, void
   if ((rc = tracer_ws(pl))) return rc;
   FieldPtrs<1> fp;
   fp.p[0] = q;
-  if ((rc = launch_project<1>(pl, fp, dtype, pl->D, nullptr, -1, pl->partial.d(), pl->sp_proj1, S_(stream)))) return rc;
-  return launch_reduce(pl, pl->partial.d(), pl->sp_proj1.nsplit, (int64_t)pl->K * pl->D, Bq, S_(stream));
+  const bool sp1 = sym_project(pl, 1);
+  rc = sp1 ? launch_project_sym<1>(pl, fp, dtype, pl->D, nullptr, -1, pl->partial.d(), pl->sp_sproj1, S_(stream))
+           : launch_project<1>(pl, fp, dtype, pl->D, nullptr, -1, pl->partial.d(), pl->sp_proj1, S_(stream));
+  if (rc) return rc;
+  return launch_reduce(pl, pl->partial.d(), sp1 ? pl->sp_sproj1.nsplit : pl->sp_proj1.nsplit,
+                       (int64_t)pl->K * pl->D, Bq, S_(stream));
 }
 
 int temx_tracer_stage2(temx_plan* pl, const void* q, const void* va, const void* wap, int dtype,
@@ -827,8 +995,7 @@ int temx_tracer_stage2(temx_plan* pl, const void* q, const void* va, const void*
   HIPCHK(hipMemcpyAsync((char*)pl->Ct.p + slab, (char*)pl->C4.p + slab, slab, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpyAsync((char*)pl->Ct.p + 2 * slab, (char*)pl->C4.p + 3 * slab, slab, hipMemcpyDeviceToDevice, st));
   if ((rc = run_eddy<1>(pl, four(q, va, wap, nullptr), dtype, pl->Ct.d(), pl->partial.d(), nullptr, st))) return rc;
-  return launch_reduce(pl, pl->partial.d(), pl->sp_eddy.nsplit * (8 / pl->sp_eddy.dpw), (int64_t)2 * pl->K * pl->D,
-                       Bq2, st);
+  return launch_reduce(pl, pl->partial.d(), eddy_slabs(pl), (int64_t)2 * pl->K * pl->D, Bq2, st);
 }
 
 int temx_tracer_stage3(temx_plan* pl, const double* Bq2, double* tres, double* tzon, void* stream) {

@@ -26,7 +26,7 @@ def _dbl(a):
 class Plan:
     """One plan per (device, native grid, output latitudes, L).  See include/temx.h."""
 
-    def __init__(self, lat_deg, lat_out_deg, L, device=0, defer_finalize=False):
+    def __init__(self, lat_deg, lat_out_deg, L, device=0, defer_finalize=False, symmetry=True):
         self._h = C.c_void_p()
         self.lib = _lib.load()
         if isinstance(device, torch.device):
@@ -39,7 +39,8 @@ class Plan:
         self.lat_out = lat_out
         self.nlev = self.nt = self.D = None
         check(self.lib.temx_plan_create(C.byref(self._h), self.device_index, self.N, self.L, self.M,
-                                        plat, plat_out, _lib.DEFER_FINALIZE if defer_finalize else 0))
+                                        plat, plat_out, (_lib.DEFER_FINALIZE if defer_finalize else 0)
+                                        | (0 if symmetry else _lib.NO_SYMMETRY)))
 
     # ---- lifetime ----
     def close(self):
