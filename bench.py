@@ -118,8 +118,9 @@ def main():
 
     # ---- shard ----
     if args.shard == "ncol" and world > 1:
-        i0, i1 = sharding.shard_bounds(ncol, world, rank)
-        lat_l, lon_l, t0_l, nt_l = lat[i0:i1], lon[i0:i1], 0, nt
+        # whole mirror pairs per rank: every rank's block of columns stays equatorially symmetric
+        mine = sharding.symmetric_ncol_shards(lat, world)[rank]
+        lat_l, lon_l, t0_l, nt_l = lat[mine], lon[mine], 0, nt
         scaling, pts_job = "strong", ncol * nlev * nt
     else:
         lat_l, lon_l, t0_l, nt_l = lat, lon, rank * nt, nt

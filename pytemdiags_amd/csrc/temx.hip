@@ -276,8 +276,12 @@ static int launch_eddy_d(temx_plan* pl, const FieldPtrs<4>& fp, const double* C,
   do {                                                                                                \
     auto kern = eddy_kernel<T, TBv, MODE, DPW, KIND>;                                                 \
     const size_t lds = ((size_t)DPW * NFR * TBv * 64 + 8 * EDDY_GR * TBv * 16) * sizeof(double);      \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
+    static bool attr_set = false;   /* once per instantiation (per process) */                        \
+    if (!attr_set) {                                                                                  \
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                 \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
+      attr_set = true;                                                                                \
+    }                                                                                                 \
     hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->N, pl->D, pl->K, pl->yblk.d(),             \
                        pl->nchunk, pl->colscale.d(), C, partial, sp.nsplit, sp.ndt, eo);              \
   } while (0)
@@ -396,8 +400,12 @@ static int launch_eddy_sym_d(temx_plan* pl, const FieldPtrs<4>& fp, const double
   do {                                                                                                \
     auto kern = eddy_sym_kernel<T, TBSv, MODE, DPW, KIND>;                                            \
     const size_t lds = ((size_t)DPW * NFR * 2 * TBSv * 64 + 8 * 2 * TBSv * 16) * sizeof(double);      \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
+    static bool attr_set = false;   /* once per instantiation (per process) */                        \
+    if (!attr_set) {                                                                                  \
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                 \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
+      attr_set = true;                                                                                \
+    }                                                                                                 \
     hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->D, pl->K, pl->K4, pl->ysym.d(),            \
                        static_cast<const int*>(pl->rows.p), pl->npg, pl->npair, pl->colscale.d(), C,  \
                        partial, sp.nsplit, sp.ndt, eo);                                               \

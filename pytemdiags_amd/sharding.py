@@ -31,6 +31,32 @@ def shard_bounds(n, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def symmetric_ncol_shards(lat_deg, world):
+    """Row index sets for ncol sharding that keep every column together with its mirror column
+    (opposite latitude), so each rank's block is itself equatorially symmetric and the engine can
+    use its mirror-paired sweeps.  Falls back to contiguous blocks if the grid is not symmetric.
+    Returns a list of ``world`` int64 index arrays (each sorted ascending)."""
+    import numpy as np
+    lat = np.asarray(lat_deg, dtype=np.float64)
+    n = lat.size
+    north = np.nonzero(lat > 1e-12)[0]
+    south = np.nonzero(lat < -1e-12)[0]
+    eq = np.nonzero(np.abs(lat) <= 1e-12)[0]
+    ok = north.size == south.size
+    if ok:
+        north = north[np.argsort(lat[north], kind="stable")]
+        south = south[np.argsort(-lat[south], kind="stable")]
+        ok = bool(np.all(np.abs(lat[north] + lat[south]) <= 1e-12))
+    if not ok:
+        return [np.arange(*shard_bounds(n, world, r), dtype=np.int64) for r in range(world)]
+    out = []
+    for r in range(world):
+        p0, p1 = shard_bounds(north.size, world, r)
+        e0, e1 = shard_bounds(eq.size, world, r)
+        out.append(np.sort(np.concatenate([north[p0:p1], south[p0:p1], eq[e0:e1]])).astype(np.int64))
+    return out
+
+
 def _world(group=None):
     if dist.is_available() and dist.is_initialized():
         return dist.get_world_size(group)

@@ -9,6 +9,13 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# libtemx.so is a build artefact (git-ignored): build it in-tree when a fresh checkout runs the
+# tests.  hipcc cross-compiles for gfx950 without a GPU.
+_LIB = os.path.join(ROOT, "pytemdiags_amd", "libtemx.so")
+if not os.path.exists(_LIB):
+    import subprocess
+    subprocess.run(["make", "-C", os.path.join(ROOT, "pytemdiags_amd", "csrc")], check=True)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -88,3 +88,19 @@ def test_shard_bounds():
     assert all(b[i][1] == b[i + 1][0] for i in range(7))
     assert [shard_bounds(777602, 8, r)[1] - shard_bounds(777602, 8, r)[0] for r in range(8)].count(97200) == 6
     assert shard_bounds(5, 8, 7) == (5, 5)
+
+
+def test_symmetric_ncol_shards():
+    from pytemdiags_amd import sharding, synth
+    lat, _ = synth.cubed_sphere_gll(4)
+    parts = sharding.symmetric_ncol_shards(lat, 3)
+    allidx = np.sort(np.concatenate(parts))
+    assert np.array_equal(allidx, np.arange(lat.size))            # a partition
+    for p in parts:
+        l = np.sort(lat[p])
+        assert np.allclose(l, -l[::-1], atol=1e-12)                # each block is mirror symmetric
+    sizes = [p.size for p in parts]
+    assert max(sizes) - min(sizes) <= 3
+    # a non-symmetric grid falls back to contiguous blocks
+    parts = sharding.symmetric_ncol_shards(np.linspace(-80, 85, 50), 4)
+    assert [int(p[0]) for p in parts] == [0, 13, 26, 38]

@@ -91,3 +91,51 @@ def test_properties_at_baseline_grid_size():
     r2, _ = plan.tem_run(*f)
     assert torch.equal(r1, r2)
     plan.close()
+
+
+def test_pole_points_and_coarse_zonal_grid_vs_oracle():
+    """zm_pole_points=True (cos(lat) ~ 6e-17 at the poles: finite but huge, exactly as numpy gives)
+    and zm_dlat=2 through the front end; the oracle implements tem_diagnostics.py:388-396."""
+    from oracle import tem_oracle as orc
+    from pytemdiags_amd import TEMDiagnostics, synth
+    lat, lon = synth.cubed_sphere_gll(8)
+    plev = synth.pressure_levels(12)
+    f = synth.analytic_fields(lat, lon, plev, 2, seed=4)
+    for pole in (False, True):
+        ref = orc.TEMOracle(*f, lat, plev, L=30, zm_dlat=2, zm_pole_points=pole, mode="factorised")
+        tem = TEMDiagnostics(*f, lat, plev=plev, L=30, zm_dlat=2, zm_pole_points=pole, debug_level=0)
+        assert tem.ZM_N == (91 if pole else 90)
+        np.testing.assert_array_equal(tem.lat, ref.lat)
+        inner = slice(1, -1) if pole else slice(None)     # the two pole rows are 1/cos blow-ups
+        for n in orc.RESULTS:
+            r, g = getattr(tem, n)(), getattr(ref, n)()
+            assert fieldnorm_err(r[inner], g[inner]) <= 1e-10, (pole, n)
+            if pole:      # same blow-up as numpy at the poles, compared relatively
+                assert np.all(np.isfinite(r) == np.isfinite(g))
+
+
+def test_pipeline_is_hip_graph_capturable():
+    """temx_tem_run is stream ordered and allocation free after set_tem: it captures into a HIP
+    graph and the replay is bit-identical to the eager run."""
+    from pytemdiags_amd import engine, synth
+    lat, lon = synth.cubed_sphere_gll(8)
+    plev = synth.pressure_levels(20)
+    lat_zm = (np.arange(-90, 91, 1.0)[1:] + np.arange(-90, 91, 1.0)[:-1]) / 2
+    plan = engine.Plan(lat, lat_zm, 50)
+    plan.set_tem(20, 3, plev * 100)
+    f = engine.synth_fields(0, lat, lon, plev, 3)
+    out = plan._alloc_results(False)
+    plan.tem_run(*f, out=out)
+    torch.cuda.synchronize()
+    ref = out[0].clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        plan.tem_run(*f, out=out)          # warm-up on the capture stream
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            plan.tem_run(*f, out=out)
+    out[0].zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], ref) and not plan.status()
+    plan.close()
