@@ -212,14 +212,21 @@ eddy_sym_kernel(FieldPtrs<4> fp, int64_t D, int K, int K4, const double* __restr
 
   // coefficient B operands, even blocks then odd blocks: cb[f][tb][lane] = C_f[harm(tb, g)][d]
   {
+    // branch free (clamped row + select) so the NB loads of a field are issued back to back; a
+    // guarded load per element serialised NFR*NB L2 round trips in every wave's prologue
     double* cb = lds + (size_t)w4 * (NFR * NB * 64) + lane;
 #pragma unroll
-    for (int f = 0; f < NFR; ++f)
+    for (int f = 0; f < NFR; ++f) {
+      double v[NB];
 #pragma unroll
       for (int tb = 0; tb < NB; ++tb) {
         const int l = sym_harm<TBS>(tb, g);
-        cb[(f * NB + tb) * 64] = l < K ? C[((int64_t)f * K4 + l) * D + dcl] : 0.0;
+        const int lc = l < K ? l : K - 1;
+        v[tb] = C[((int64_t)f * K4 + lc) * D + dcl];
       }
+#pragma unroll
+      for (int tb = 0; tb < NB; ++tb) cb[(f * NB + tb) * 64] = sym_harm<TBS>(tb, g) < K ? v[tb] : 0.0;
+    }
   }
   int cbi = w4 * (NFR * NB * 64) + lane;
   double* yst = lds + DPW * NFR * NB * 64 + wave * YE;
