@@ -184,7 +184,7 @@ def main():
         "config": {"workload": "ne%d (%d cols) x %d lev x %d snapshots per %s, L=50, 1-degree zonal grid (M=180), "
                                "ten GM16 Table-A1 outputs" % (ne, ncol, nlev, nt, "GPU" if scaling == "weak" else "job"),
                    "shard": args.shard if world > 1 else "none", "ncol": int(ncol), "nlev": nlev, "nt": nt,
-                   "mirror_paired_sweeps": bool(not args.no_symmetry)},
+                   "mirror_paired_sweeps": bool(plan.paired)},
         "plan_build_s": plan_s,
         "pipeline_frac_of_fp64_roofline": value / world / (PEAK_F64_TFLOPS * 1e12 / FLOPS_PER_PT),
         "nonfinite": bool(nonfinite),

@@ -104,6 +104,9 @@ int temx_plan_set_weights(temx_plan* plan, const double* weights_host /* [ncol],
 
 void temx_plan_destroy(temx_plan* plan);
 
+/* 1 if the plan runs the mirror-paired sweeps (equatorially symmetric grid detected), else 0. */
+int temx_plan_is_paired(const temx_plan* plan);
+
 int temx_get_matrix(temx_plan* plan, int which, double* dst, void* stream);
 
 /* ---- operator API: replaces _sph_zonal_mean_generic (sph_zonal_mean.py:187-283) ------------ */

@@ -685,6 +685,8 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
   return TEMX_OK;
 }
 
+int temx_plan_is_paired(const temx_plan* pl) { return pl && pl->sym ? 1 : 0; }
+
 int temx_plan_finalize(temx_plan* pl, const double* G_host) {
   if (!pl) return fail(TEMX_EINVAL, "null plan");
   HIPCHK(hipSetDevice(pl->device));

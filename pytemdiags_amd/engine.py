@@ -42,6 +42,11 @@ class Plan:
                                         plat, plat_out, (_lib.DEFER_FINALIZE if defer_finalize else 0)
                                         | (0 if symmetry else _lib.NO_SYMMETRY)))
 
+    @property
+    def paired(self):
+        """True when the mirror-paired sweeps are in use (equatorially symmetric grid)."""
+        return bool(self.lib.temx_plan_is_paired(self._h))
+
     # ---- lifetime ----
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
