@@ -123,18 +123,20 @@ project_sym_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
     for (int j = 0; j < YJ; ++j) ys[j] = (ysym + (int64_t)chunk * YE)[(tid + 256 * j) < YE ? (tid + 256 * j) : 0];
   };
 
-  if (c0 >= c1) return;
+  // (an empty range still stores its zero slab below: the reduction sums every slab)
   int has_s[CH];
-  load_ys(c0);
-  load_rows(c0);
-  if (active) {
+  if (c0 < c1) {
+    load_ys(c0);
+    load_rows(c0);
+    if (active) {
 #pragma unroll
-    for (int ti = 0; ti < CH; ++ti) {
-      load_x(ti);
-      has_s[ti] = rs[ti] >= 0;
+      for (int ti = 0; ti < CH; ++ti) {
+        load_x(ti);
+        has_s[ti] = rs[ti] >= 0;
+      }
     }
+    load_rows(c0 + 1);        // padded: always in bounds
   }
-  load_rows(c0 + 1);        // padded: always in bounds
   for (int chunk = c0; chunk < c1; ++chunk) {
     double* yst = ystage[(chunk - c0) & 1];
 #pragma unroll
@@ -244,10 +246,11 @@ eddy_sym_kernel(FieldPtrs<4> fp, int64_t D, int K, int K4, const double* __restr
 #pragma unroll
     for (int t = 0; t < NB; ++t) acc[q][t] = 0.0;
 
-  if (c0 >= c1) return;
+  // (an empty range still stores its zero slab below: the reduction sums every slab)
   T xn[NFR], xs[NFR];
   double ys[YJ];
-  int rn = rows[(int64_t)c0 * 4 + g], rs = rows[npg4 + (int64_t)c0 * 4 + g];
+  const int64_t cs = c0 < c1 ? c0 : 0;
+  int rn = rows[cs * 4 + g], rs = rows[npg4 + cs * 4 + g];
   auto load_x = [&]() __attribute__((always_inline)) {
     const int64_t on = (int64_t)rn * D;
     const int64_t os = (int64_t)(rs < 0 ? rn : rs) * D;
@@ -261,11 +264,11 @@ eddy_sym_kernel(FieldPtrs<4> fp, int64_t D, int K, int K4, const double* __restr
 #pragma unroll
     for (int j = 0; j < YJ; ++j) ys[j] = (ysym + (int64_t)step * YE)[(lane + 64 * j) < YE ? (lane + 64 * j) : 0];
   };
-  load_ys(c0);
+  load_ys((int)cs);
   load_x();
   int crn = rn, crs = rs;                              // rows of the step whose X is in xn/xs
-  rn = rows[(int64_t)(c0 + 1) * 4 + g];                // padded: in bounds
-  rs = rows[npg4 + (int64_t)(c0 + 1) * 4 + g];
+  rn = rows[(cs + 1) * 4 + g];                         // padded: in bounds
+  rs = rows[npg4 + (cs + 1) * 4 + g];
 
   for (int step = c0; step < c1; ++step) {
 #pragma unroll

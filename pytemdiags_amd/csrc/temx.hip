@@ -160,22 +160,12 @@ static void time_end(temx_plan* pl, int which, hipStream_t st, TimedLaunch& tl) 
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-// sweep-1 configuration: fields per wave, X ring depth, waves per SIMD
-struct ProjCfgA { static constexpr int NFW = 2, PD = 2, WPS = 3; };
-struct ProjCfgB { static constexpr int NFW = 2, PD = 3, WPS = 2; };
-struct ProjCfgC { static constexpr int NFW = 4, PD = 1, WPS = 2; };
-struct ProjCfgD { static constexpr int NFW = 2, PD = 1, WPS = 3; };
-struct ProjCfgE { static constexpr int NFW = 1, PD = 2, WPS = 3; };   // small D: one d-tile per workgroup
-struct ProjCfg1 { static constexpr int NFW = 1, PD = 2, WPS = 2; };
-static int proj_cfg_id() {
-  static int id = -1;
-  if (id < 0) {
-    const char* e = getenv("TEMX_PROJ_CFG");
-    id = e ? (e[0] - 'A') : 2;   // default C: 4 fields per wave, measured best by a hair
-    if (id < 0 || id > 3) id = 0;
-  }
-  return id;
-}
+// sweep-1 configurations (fields per wave, X ring depth, waves per SIMD).  Measured on
+// ne120x72x30: 2 fields/wave with 2- or 3-deep rings at 3 waves/SIMD were within +-3 % of this.
+struct ProjCfgC { static constexpr int NFW = 4, PD = 1, WPS = 2; };   // default: quads of d-tiles
+struct ProjCfgE { static constexpr int NFW = 1, PD = 2, WPS = 3; };   // small ragged D: one d-tile per workgroup
+struct ProjCfg1 { static constexpr int NFW = 1, PD = 2, WPS = 2; };   // single-field operator API / Gram
+
 // d-tiles per workgroup that waste the fewest wave slots on a ragged last workgroup
 static int pick_dpw(int ndt, int maxdpw) {
   int best = maxdpw;
@@ -191,15 +181,11 @@ static int pick_dpw(int ndt, int maxdpw) {
 }
 static int proj_dpw(int NF, int ndt) {
   if (NF == 1) return 4;
-  const int nfw[4] = {ProjCfgA::NFW, ProjCfgB::NFW, ProjCfgC::NFW, ProjCfgD::NFW};
-  const int d = 4 * nfw[proj_cfg_id()] / 4;
-  return pick_dpw(ndt, d) == 1 ? 1 : d;     // small ragged D: config E (1 field per wave)
+  return pick_dpw(ndt, 4) == 1 ? 1 : 4;     // small ragged D: config E (1 field per wave)
 }
 static int proj_wps(int NF, int dpw) {
-  if (NF == 1) return 2;
-  if (dpw == 1) return ProjCfgE::WPS;
-  const int w[4] = {ProjCfgA::WPS, ProjCfgB::WPS, ProjCfgC::WPS, ProjCfgD::WPS};
-  return w[proj_cfg_id()];
+  if (NF == 1) return ProjCfg1::WPS;
+  return dpw == 1 ? ProjCfgE::WPS : ProjCfgC::WPS;
 }
 
 template <typename T, int NF, typename Cfg>
@@ -228,12 +214,7 @@ static int launch_project_t(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t D, c
     return launch_project_c<T, NF, ProjCfg1>(pl, fp, D, colscale, sfield, partial, sp, st);
   } else {
     if (sp.dpw == 1) return launch_project_c<T, NF, ProjCfgE>(pl, fp, D, colscale, sfield, partial, sp, st);
-    switch (proj_cfg_id()) {
-      case 1: return launch_project_c<T, NF, ProjCfgB>(pl, fp, D, colscale, sfield, partial, sp, st);
-      case 2: return launch_project_c<T, NF, ProjCfgC>(pl, fp, D, colscale, sfield, partial, sp, st);
-      case 3: return launch_project_c<T, NF, ProjCfgD>(pl, fp, D, colscale, sfield, partial, sp, st);
-      default: return launch_project_c<T, NF, ProjCfgA>(pl, fp, D, colscale, sfield, partial, sp, st);
-    }
+    return launch_project_c<T, NF, ProjCfgC>(pl, fp, D, colscale, sfield, partial, sp, st);
   }
 }
 

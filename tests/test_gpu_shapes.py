@@ -139,3 +139,29 @@ def test_pipeline_is_hip_graph_capturable():
     torch.cuda.synchronize()
     assert torch.equal(out[0], ref) and not plan.status()
     plan.close()
+
+
+@pytest.mark.parametrize("lat", [
+    np.array([-61.0, -20.5, 3.0, 17.25, 44.0, 71.5, 88.0]),            # 7 columns, not symmetric
+    np.array([-70.0, -35.5, -10.0, 0.0, 10.0, 35.5, 70.0]),            # symmetric with an equator column
+    np.array([-80.0, 80.0, -45.0, 45.0, -5.0, 5.0]),                   # symmetric, unordered, no equator
+    np.linspace(-85, 85, 19),                                          # 19 columns (one ragged group)
+])
+def test_tiny_grids(lat):
+    """Fewer columns than one chunk, counts that are not multiples of 4, both sweep flavours."""
+    from oracle import tem_oracle as orc
+    from pytemdiags_amd import _lib, engine
+    rng = np.random.default_rng(1)
+    N, nlev, nt, L = lat.size, 5, 3, 3
+    plev = np.array([50.0, 150.0, 400.0, 700.0, 950.0])
+    f = [rng.standard_normal((N, nlev, nt)) + off for off in (0, 0, 280, 0)]
+    ref = orc.TEMOracle(*f, lat, plev, L=L, zm_dlat=10, mode="factorised")
+    for symmetry in (True, False):
+        plan = engine.Plan(lat, ref.lat, L, symmetry=symmetry)
+        plan.set_tem(nlev, nt, plev * 100)
+        res, _ = plan.tem_run(*[torch.as_tensor(x, device="cuda:0") for x in f])
+        assert not plan.status()
+        res = res.cpu().numpy()
+        for i, n in enumerate(_lib.RESULT_NAMES):
+            assert fieldnorm_err(res[i], getattr(ref, n)()) <= 1e-10, (symmetry, plan.paired, n)
+        plan.close()
