@@ -165,3 +165,49 @@ def test_tiny_grids(lat):
         for i, n in enumerate(_lib.RESULT_NAMES):
             assert fieldnorm_err(res[i], getattr(ref, n)()) <= 1e-10, (symmetry, plan.paired, n)
         plan.close()
+
+
+@pytest.mark.parametrize("symmetric_shards", [True, False])
+def test_ncol_sharded_flow_emulated_on_one_gpu(symmetric_shards):
+    """The staged C ABI as NcolShardedTEM drives it, with the all-reduces replaced by explicit sums
+    over two 'ranks' that live on the same GPU: Gram, [4][K][D] sums, [3][K][D] flux sums, tracer
+    sums.  Must reproduce the unsharded run."""
+    from pytemdiags_amd import _lib, engine, sharding, synth
+    lat, lon = synth.cubed_sphere_gll(8)
+    plev = synth.pressure_levels(10)
+    nt = 3
+    lat_zm = (np.arange(-90, 91, 1.0)[1:] + np.arange(-90, 91, 1.0)[:-1]) / 2
+    f = [torch.as_tensor(x, device="cuda:0") for x in synth.analytic_fields(lat, lon, plev, nt, seed=9)]
+    q = torch.as_tensor(synth.analytic_tracer(lat, lon, plev, nt), device="cuda:0")
+    full = engine.Plan(lat, lat_zm, 50)
+    full.set_tem(10, nt, plev * 100)
+    ref, _ = full.tem_run(*f)
+    tref, _ = full.tracer_run(q, f[1], f[3])
+
+    if symmetric_shards:
+        parts = sharding.symmetric_ncol_shards(lat, 2)
+    else:
+        parts = [np.arange(*sharding.shard_bounds(lat.size, 2, r)) for r in range(2)]
+    plans = [engine.Plan(lat[p], lat_zm, 50, defer_finalize=True) for p in parts]
+    assert [pl.paired for pl in plans] == [symmetric_shards] * 2
+    G = sum(pl.matrix(_lib.MAT_GRAM) for pl in plans)                   # all-reduce (i)
+    loc = []
+    for pl, p in zip(plans, parts):
+        pl.finalize(G.cpu().numpy())
+        pl.set_tem(10, nt, plev * 100)
+        idx = torch.as_tensor(p, device="cuda:0")
+        loc.append([x[idx].contiguous() for x in f] + [q[idx].contiguous()])
+    B4 = sum(pl.tem_stage1(*l[:4]) for pl, l in zip(plans, loc))        # all-reduce (ii)
+    B3 = sum(pl.tem_stage2(*l[:4], B4) for pl, l in zip(plans, loc))    # all-reduce (iii)
+    for pl in plans:                                                    # every rank: same epilogue
+        res, _ = pl.tem_stage3(B3)
+        for i, n in enumerate(_lib.RESULT_NAMES):
+            assert fieldnorm_err(res[i].cpu().numpy(), ref[i].cpu().numpy()) <= 1e-11, n
+    Bq = sum(pl.tracer_stage1(l[4]) for pl, l in zip(plans, loc))
+    Bq2 = sum(pl.tracer_stage2(l[4], l[1], l[3], Bq) for pl, l in zip(plans, loc))
+    tres, _ = plans[0].tracer_stage3(Bq2)
+    for i, n in enumerate(_lib.TRACER_RESULT_NAMES):
+        assert fieldnorm_err(tres[i].cpu().numpy(), tref[i].cpu().numpy()) <= 1e-11, n
+    assert not any(pl.status() for pl in plans)
+    for pl in plans + [full]:
+        pl.close()
