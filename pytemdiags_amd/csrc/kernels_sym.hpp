@@ -22,6 +22,8 @@
 
 namespace temx {
 
+constexpr int SYM_PROJ_CH = 3;   // pair-groups per chunk of the paired project sweep
+
 __global__ void sym_basis_kernel(const double* __restrict__ x, const int* __restrict__ rowN, int64_t npair,
                                  int64_t npair_pad, int K, int TBS, const double* __restrict__ norm,
                                  double* __restrict__ ysym) {
@@ -64,10 +66,10 @@ __device__ __forceinline__ constexpr int sym_harm(int tb, int i) {
 template <typename T, int NF, int TBS>
 __global__ void __launch_bounds__(256, 2)
 project_sym_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict__ ysym,
-                   const int* __restrict__ rows, int64_t npg, const double* __restrict__ colscale,
+                   const int* __restrict__ rows, int64_t npg, int64_t npg4, const double* __restrict__ colscale,
                    int sfield, double* __restrict__ partial, int nsplit, int ndt) {
   constexpr int NB = 2 * TBS;                 // blocks per pair-group
-  constexpr int CH = 2;                       // pair-groups per chunk (16 physical rows)
+  constexpr int CH = SYM_PROJ_CH;             // pair-groups per chunk (CH*8 physical rows)
   constexpr int YE = CH * NB * 16;
   constexpr int YJ = (YE + 255) / 256;
   __shared__ double ystage[2][YE];
@@ -81,9 +83,8 @@ project_sym_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
   const int64_t d = (int64_t)dt * 16 + c;
   const bool dvalid = active && d < D;
   const int64_t dcl = d < D ? d : D - 1;
-  const int64_t nchunk = (npg + CH - 1) / CH;             // rows[] and ysym are padded to whole chunks (+1)
+  const int64_t nchunk = (npg + CH - 1) / CH;             // rows[] and ysym are padded to whole chunks (+1); npg4 = entries per half of rows[]
   const int c0 = (int)(nchunk * split / nsplit), c1 = (int)(nchunk * (split + 1) / nsplit);
-  const int64_t npg4 = (nchunk + 1) * CH * 4;             // entries per half of rows[]
   const uint32_t yoff = (uint32_t)(g * 4 + (lane & 3));
 
   double sc[NF];
@@ -188,7 +189,8 @@ project_sym_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
 template <typename T, int TBS, int MODE, int DPW, int KIND>
 __global__ void __launch_bounds__(512, 2)
 eddy_sym_kernel(FieldPtrs<4> fp, int64_t D, int K, int K4, const double* __restrict__ ysym,
-                const int* __restrict__ rows, int64_t npg, int64_t npair, const double* __restrict__ colscale,
+                const int* __restrict__ rows, int64_t npg, int64_t npg4, int64_t npair,
+                const double* __restrict__ colscale,
                 const double* __restrict__ C, double* __restrict__ partial, int nsplit, int ndt,
                 EddyOut eo) {
   extern __shared__ double lds[];
@@ -210,7 +212,6 @@ eddy_sym_kernel(FieldPtrs<4> fp, int64_t D, int K, int K4, const double* __restr
   const int64_t dcl = dvalid ? d : D - 1;
   const int64_t sub = (int64_t)split * NP + part, nsub = (int64_t)nsplit * NP;
   const int c0 = (int)(npg * sub / nsub), c1 = (int)(npg * (sub + 1) / nsub);
-  const int64_t npg4 = (((npg + 1) / 2) + 1) * 2 * 4;       // entries per half of rows[] (see host)
 
   // coefficient B operands, even blocks then odd blocks: cb[f][tb][lane] = C_f[harm(tb, g)][d]
   {

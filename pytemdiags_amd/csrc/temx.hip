@@ -350,8 +350,8 @@ static int launch_project_sym_t(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t 
   dim3 grid(sp.grid), block(256);
 #define TEMX_LPS(TBSv)                                                                              \
   hipLaunchKernelGGL((project_sym_kernel<T, NF, TBSv>), grid, block, 0, st, fp, D, pl->K,           \
-                     pl->ysym.d(), static_cast<const int*>(pl->rows.p), pl->npg, colscale, sfield,  \
-                     partial, sp.nsplit, sp.ndt)
+                     pl->ysym.d(), static_cast<const int*>(pl->rows.p), pl->npg, pl->npg_alloc * 4, \
+                     colscale, sfield, partial, sp.nsplit, sp.ndt)
   switch (pl->TBS) {
     case 2: TEMX_LPS(2); break;
     case 4: TEMX_LPS(4); break;
@@ -388,8 +388,8 @@ static int launch_eddy_sym_d(temx_plan* pl, const FieldPtrs<4>& fp, const double
       attr_set = true;                                                                                \
     }                                                                                                 \
     hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->D, pl->K, pl->K4, pl->ysym.d(),            \
-                       static_cast<const int*>(pl->rows.p), pl->npg, pl->npair, pl->colscale.d(), C,  \
-                       partial, sp.nsplit, sp.ndt, eo);                                               \
+                       static_cast<const int*>(pl->rows.p), pl->npg, pl->npg_alloc * 4, pl->npair,    \
+                       pl->colscale.d(), C, partial, sp.nsplit, sp.ndt, eo);                          \
   } while (0)
   switch (pl->TBS) {
     case 2: TEMX_LES(2); break;
@@ -641,7 +641,7 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
       pl->TBS = tbs <= 2 ? 2 : (tbs <= 4 ? 4 : (tbs <= 7 ? 7 : 8));
       pl->npair = (int64_t)rN.size();
       pl->npg = (pl->npair + 3) / 4;
-      pl->npg_alloc = ((pl->npg + 1) / 2 + 1) * 2;             // whole chunks of 2 groups + 1 chunk
+      pl->npg_alloc = ((pl->npg + SYM_PROJ_CH - 1) / SYM_PROJ_CH + 1) * SYM_PROJ_CH;   // whole chunks + 1 chunk
       const int64_t n4 = pl->npg_alloc * 4;
       std::vector<int> rows((size_t)2 * n4, 0);
       for (int64_t k = 0; k < n4; ++k) rows[(size_t)n4 + k] = -1;
@@ -843,7 +843,7 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
   if ((rc = pl->zb.ensure((size_t)8 * M * D * 8))) return rc;
   pl->sp_proj1 = choose_split(D, pl->nchunk, 2 * pl->num_cu);
   if (pl->sym) {
-    const int64_t nch = (pl->npg + 1) / 2;
+    const int64_t nch = (pl->npg + SYM_PROJ_CH - 1) / SYM_PROJ_CH;
     pl->sp_sproj4 = Split();
     pl->sp_sproj1 = Split();
     if (pick_dpw(ndt_, 4) == 4) {     // the paired project sweep is built for quads of d-tiles
