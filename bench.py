@@ -117,7 +117,8 @@ def main():
     ncol = lat.size
 
     # ---- shard ----
-    if args.shard == "ncol" and world > 1:
+    use_ncol = args.shard == "ncol"          # at world 1 the all-reduces are no-ops (path check)
+    if use_ncol:
         # whole mirror pairs per rank: every rank's block of columns stays equatorially symmetric
         mine = sharding.symmetric_ncol_shards(lat, world)[rank]
         lat_l, lon_l, t0_l, nt_l = lat[mine], lon[mine], 0, nt
@@ -129,9 +130,9 @@ def main():
     # ---- plan (timed separately; the reference amortises it through its map cache) ----
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    plan = engine.Plan(lat_l, lat_zm, K_HARM - 1, device=local_rank, defer_finalize=(args.shard == "ncol" and world > 1),
+    plan = engine.Plan(lat_l, lat_zm, K_HARM - 1, device=local_rank, defer_finalize=use_ncol,
                        symmetry=not args.no_symmetry)
-    if args.shard == "ncol" and world > 1:
+    if use_ncol:
         runner = sharding.NcolShardedTEM(plan)
     plan.set_tem(nlev, nt_l, plev * 100)
     torch.cuda.synchronize()
@@ -140,7 +141,7 @@ def main():
     fields = engine.synth_fields(local_rank, lat_l, lon_l, plev, nt_l, t0=t0_l, dtype=tdtype, seed=0)
     out = plan._alloc_results(False)
 
-    if args.shard == "ncol" and world > 1:
+    if use_ncol:
         def step():
             return runner.run(*fields)
     else:
@@ -183,7 +184,7 @@ def main():
         "scaling": scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "ne%d (%d cols) x %d lev x %d snapshots per %s, L=50, 1-degree zonal grid (M=180), "
                                "ten GM16 Table-A1 outputs" % (ne, ncol, nlev, nt, "GPU" if scaling == "weak" else "job"),
-                   "shard": args.shard if world > 1 else "none", "ncol": int(ncol), "nlev": nlev, "nt": nt,
+                   "shard": args.shard if (world > 1 or use_ncol) else "none", "ncol": int(ncol), "nlev": nlev, "nt": nt,
                    "mirror_paired_sweeps": bool(plan.paired)},
         "plan_build_s": plan_s,
         "pipeline_frac_of_fp64_roofline": value / world / (PEAK_F64_TFLOPS * 1e12 / FLOPS_PER_PT),
