@@ -82,10 +82,10 @@ __device__ __forceinline__ int uniform_wave() {
   return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // SGPR: addresses stay scalar
 }
 
-// workgroup-work decomposition shared by the sweeps: work id -> (split over chunks, quad of
-// d-tiles).  The 4 (x2) waves of a workgroup walk the same chunk range in lockstep (one barrier
-// per step) and share its Y0 blocks through LDS.  Workgroups are dealt to XCDs round-robin
-// (blockIdx % 8); remapping so that each XCD owns a contiguous run of work ids keeps the quads of
+// workgroup-work decomposition shared by the sweeps: work id -> (split over chunks, group of
+// d-tiles).  The waves of a workgroup walk the same chunk range of the same group of d-tiles.
+// Workgroups are dealt to XCDs round-robin
+// (blockIdx % 8); remapping so that each XCD owns a contiguous run of work ids keeps the groups of
 // one chunk range (which stream the same Y0 blocks) behind one L2.
 __device__ __forceinline__ bool wg_work(int ndq, int nsplit, int& split, int& dq) {
   const int cpx = gridDim.x >> 3;
@@ -101,9 +101,11 @@ __device__ __forceinline__ bool wg_work(int ndq, int nsplit, int& split, int& dq
 // Replaces the inner np.matmul(Y0inv, AA) of sph_zonal_mean.py:251 (reduction over ncol); the
 // G^-1 factor is applied afterwards on the K x D sums (solve_kernel).  For the TEM pipeline NF=4
 // with theta = T (p0/p)^kappa fused into the load of field `sfield` (tem_diagnostics.py:498).
-// One wave owns one d-tile and all TB l-blocks of all NF fields (NF*TB accumulator registers);
-// no LDS, no barriers.  X is read exactly once from HBM, re-loaded one chunk ahead into the
-// registers it has just been consumed from; Y0 blocks (L2) run TB operands ahead in a ring.
+// One wave owns one d-tile, all TB l-blocks and NFW of the NF fields (NFW*TB accumulator
+// registers).  X is read exactly once from HBM in the MFMA B layout, straight into registers, PD
+// chunks ahead (re-loaded into the registers just consumed).  The Y0 blocks of a chunk are staged
+// through LDS by the whole workgroup (double buffered, one barrier per chunk): loaded per operand
+// they would make every wait also wait for the youngest HBM loads (vector loads retire in order).
 // ------------------------------------------------------------------------------------------------
 template <typename T, int NF, int NFW, int TB, int PD, int WPS>
 __global__ void __launch_bounds__(256, WPS)
@@ -318,18 +320,18 @@ solve_kernel(const double* __restrict__ B, int K, int K4, int M, int64_t D,
 }
 
 // ------------------------------------------------------------------------------------------------
-// eddy / flux sweep (the dominant kernel).  Per chunk (16 columns) x d-tile (16), one wave:
+// eddy / flux sweep (the dominant kernel).  Per step (8 columns) x d-tile (16), one wave:
 //   xbar_f = Y0[chunk] . C_f                (4 reconstructions; contraction over harmonics)
 //            = sph_zonal_mean_native of tem_diagnostics.py:517-529, never stored
 //   x'_f   = x_f - xbar_f                    (eddies; theta = T (p0/p)^kappa fused in the load)
 //   u'v', u'w', v'theta'                     (tem_diagnostics.py:547-555)
 //   partial[q][l][d] += Y0[chunk]^T . (product q)    (3 projections; contraction over columns)
-// = 8*TB A operands and 28*TB MFMAs per chunk.  The reconstruction result tile has the B-operand
-// layout, so the products feed the projection with no lane movement.
+// = 14*TB MFMAs per step.  The reconstruction result tile has the B-operand layout, so the products
+// feed the projection with no lane movement.
 // The coefficient B operands (4 fields x TB k-steps x 16 columns) are loop invariant per d-tile;
-// they live in an LDS slab shared by the two waves (wave, wave+4) that split the chunk range of
-// that d-tile.  Each wave writes the whole slab itself before reading it (identical values from
-// both writers), so no barrier is needed anywhere.  Y0 blocks arrive through a TB-deep ring.
+// they live in an LDS slab shared by the 8/DPW waves that split the step range of that d-tile.
+// Each wave writes the whole slab itself before reading it (identical values from every writer),
+// so no barrier is needed anywhere.
 // MODE 1 additionally stores the eddies / products (lazy properties up, vp, ... of :420-433).
 // ------------------------------------------------------------------------------------------------
 constexpr int EDDY_GR = 2;   // groups (of 4 columns) per eddy step: 8 columns x 16 (lev,time)
