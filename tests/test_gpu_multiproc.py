@@ -1,0 +1,104 @@
+"""Two real processes on one GPU: the product sharding drivers (pytemdiags_amd/sharding.py) with the
+HIP engine as backend and torch.distributed collectives between the ranks (gloo backend, which
+all-reduces device tensors; both ranks share cuda:0 -- RCCL itself needs one GPU per rank).
+Checks ncol sharding (mirror-symmetric shards, 5 all-reduces incl. the tracer) and time sharding
+(no data-path collective, ragged gather) against the unsharded run on the same inputs."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NE, NLEV, NT = 8, 12, 5
+
+
+def _inputs():
+    from pytemdiags_amd import synth
+    lat, lon = synth.cubed_sphere_gll(NE)
+    plev = synth.pressure_levels(NLEV)
+    f = synth.analytic_fields(lat, lon, plev, NT, seed=21)
+    q = synth.analytic_tracer(lat, lon, plev, NT)
+    lat_zm = (np.arange(-90, 91, 1.0)[1:] + np.arange(-90, 91, 1.0)[:-1]) / 2
+    return lat, plev, f, q, lat_zm
+
+
+def _worker(rank, world, port, mode, ret):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from pytemdiags_amd import engine, sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lat, plev, f, q, lat_zm = _inputs()
+        dev = lambda x: torch.as_tensor(np.ascontiguousarray(x), device="cuda:0")   # noqa: E731
+        if mode == "ncol":
+            mine = sharding.symmetric_ncol_shards(lat, world)[rank]
+            plan = engine.Plan(lat[mine], lat_zm, 50, defer_finalize=True)
+            runner = sharding.NcolShardedTEM(plan)
+            plan.set_tem(NLEV, NT, plev * 100)
+            loc = [dev(x[mine]) for x in f]
+            res, _ = runner.run(*loc)
+            tres, _ = runner.run_tracer(dev(q[mine]), loc[1], loc[3])
+            out = torch.cat([res, tres])
+            paired = plan.paired
+        else:
+            plan = engine.Plan(lat, lat_zm, 50)
+            runner = sharding.TimeShardedTEM(plan, NT)
+            t0, t1 = runner.t0, runner.t1
+            plan.set_tem(NLEV, t1 - t0, plev * 100)
+            res, _ = runner.run(*[dev(x[:, :, t0:t1]) for x in f])
+            out = sharding.gather_time(res)
+            paired = plan.paired
+        bad = plan.status()
+        plan.close()
+        if rank == 0:
+            ret.put((out.cpu().numpy(), bool(paired), bool(bad)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("mode", ["ncol", "time"])
+def test_two_ranks_on_one_gpu(mode):
+    import torch.multiprocessing as mp
+    from pytemdiags_amd import engine
+    lat, plev, f, q, lat_zm = _inputs()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, paired, bad = ret.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert paired and not bad
+    # unsharded reference run in this process
+    plan = engine.Plan(lat, lat_zm, 50)
+    plan.set_tem(NLEV, NT, plev * 100)
+    d = [torch.as_tensor(x, device="cuda:0") for x in f]
+    ref, _ = plan.tem_run(*d)
+    ref = ref.cpu().numpy()
+    if mode == "ncol":
+        tref, _ = plan.tracer_run(torch.as_tensor(q, device="cuda:0"), d[1], d[3])
+        ref = np.concatenate([ref, tref.cpu().numpy()])
+    plan.close()
+    assert got.shape == ref.shape
+    for i in range(ref.shape[0]):
+        err = np.max(np.abs(got[i] - ref[i])) / np.max(np.abs(ref[i]))
+        assert err <= 1e-11, (mode, i, err)
