@@ -38,7 +38,8 @@ enum {
   TEMX_EINVAL = -1,   /* bad argument */
   TEMX_EHIP = -2,     /* HIP runtime error (no device, launch failure, ...) */
   TEMX_ENOMEM = -3,   /* device allocation failed */
-  TEMX_ERANK = -4,    /* Gram matrix not positive definite (rank-deficient Y0) */
+  TEMX_ERANK = -4,    /* Gram matrix has no positive eigenvalue (a rank-deficient Y0 is handled by a
+                         pseudo-inverse, like the reference's lstsq) */
   TEMX_ESTATE = -5,   /* call order violated (plan not finalised, TEM levels not set, ...) */
   TEMX_EUNSUPPORTED = -6
 };

@@ -81,6 +81,7 @@ struct temx_plan {
   int64_t N = 0, nchunk = 0;
   int L = 0, K = 0, TB = 0, K4 = 0, M = 0;
   bool finalized = false;
+  int rank = 0;               // numerical rank of Y0 (== K unless the pseudo-inverse fallback ran)
   DevBuf x, Y0, yblk, yblk_w, Y0p, G, Ginv, norm, flag;
   const double* yproj_ptr() const { return yblk_w.p ? yblk_w.d() : yblk.d(); }
   std::vector<double> lat_out_deg;
@@ -448,6 +449,63 @@ static int spd_inverse(const double* G, int K, double* Ginv) {
   return 0;
 }
 
+// Pseudo-inverse of the symmetric positive semi-definite Gram matrix by cyclic Jacobi rotations
+// (K <= 64).  Used when Cholesky fails: pinv(Y0) = pinv(G) Y0^T holds for any rank, which is the
+// minimum-norm semantics of the reference's lstsq (gelsd) for a rank-deficient Y0 -- fewer distinct
+// latitudes than harmonics.  Eigenvalues below 1e-12 * lambda_max are treated as zero.
+static int sym_pinv(const double* G, int K, double* Ginv, int* rank_out) {
+  std::vector<long double> A((size_t)K * K), V((size_t)K * K, 0.0L);
+  for (int i = 0; i < K * K; ++i) A[i] = G[i];
+  for (int i = 0; i < K; ++i) V[(size_t)i * K + i] = 1.0L;
+  for (int sweep = 0; sweep < 100; ++sweep) {
+    long double off = 0.0L, diag = 0.0L;
+    for (int i = 0; i < K; ++i)
+      for (int j = 0; j < K; ++j) (i == j ? diag : off) += A[(size_t)i * K + j] * A[(size_t)i * K + j];
+    if (off <= 1e-60L * diag) break;
+    for (int p = 0; p < K - 1; ++p)
+      for (int q = p + 1; q < K; ++q) {
+        const long double apq = A[(size_t)p * K + q];
+        if (apq == 0.0L) continue;
+        const long double theta = (A[(size_t)q * K + q] - A[(size_t)p * K + p]) / (2.0L * apq);
+        const long double t = (theta >= 0 ? 1.0L : -1.0L) / (fabsl(theta) + sqrtl(theta * theta + 1.0L));
+        const long double c = 1.0L / sqrtl(t * t + 1.0L), sn = t * c;
+        for (int k = 0; k < K; ++k) {   // A <- A J
+          const long double akp = A[(size_t)k * K + p], akq = A[(size_t)k * K + q];
+          A[(size_t)k * K + p] = c * akp - sn * akq;
+          A[(size_t)k * K + q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < K; ++k) {   // A <- J^T A
+          const long double apk = A[(size_t)p * K + k], aqk = A[(size_t)q * K + k];
+          A[(size_t)p * K + k] = c * apk - sn * aqk;
+          A[(size_t)q * K + k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < K; ++k) {   // V <- V J
+          const long double vkp = V[(size_t)k * K + p], vkq = V[(size_t)k * K + q];
+          V[(size_t)k * K + p] = c * vkp - sn * vkq;
+          V[(size_t)k * K + q] = sn * vkp + c * vkq;
+        }
+      }
+  }
+  long double lmax = 0.0L;
+  for (int i = 0; i < K; ++i) lmax = std::max(lmax, A[(size_t)i * K + i]);
+  if (!(lmax > 0.0L)) return -1;
+  int rank = 0;
+  std::vector<long double> inv(K, 0.0L);
+  for (int i = 0; i < K; ++i)
+    if (A[(size_t)i * K + i] > 1e-12L * lmax) {
+      inv[i] = 1.0L / A[(size_t)i * K + i];
+      ++rank;
+    }
+  for (int i = 0; i < K; ++i)
+    for (int j = 0; j < K; ++j) {
+      long double s2 = 0.0L;
+      for (int k = 0; k < K; ++k) s2 += V[(size_t)i * K + k] * inv[k] * V[(size_t)j * K + k];
+      Ginv[(size_t)i * K + j] = (double)s2;
+    }
+  *rank_out = rank;
+  return 0;
+}
+
 // np.gradient(f, x) coefficient table out[i] = a f[i-1] + b f[i] + c f[i+1], edge_order = 1
 // (tem_util.py:154, 192).  numpy switches to the uniform formula only when diff(x) is bit-uniform.
 static void gradient_table(const std::vector<double>& x, std::vector<double>& tab) {
@@ -681,9 +739,15 @@ int temx_plan_finalize(temx_plan* pl, const double* G_host) {
   }
   for (double v : G)
     if (!std::isfinite(v)) return fail(TEMX_EINVAL, "Gram matrix is not finite (NaN latitudes?)");
-  if (spd_inverse(G.data(), K, Gi.data()) != 0)
-    return fail(TEMX_ERANK, "Y0^T Y0 is not positive definite: Y0 (N=%lld, K=%d) is rank deficient "
-                "(fewer distinct latitudes than harmonics?)", (long long)pl->N, K);
+  if (spd_inverse(G.data(), K, Gi.data()) != 0) {
+    // rank-deficient Y0: pseudo-inverse, like the reference's lstsq (sph_zonal_mean.py:389)
+    int rank = 0;
+    if (sym_pinv(G.data(), K, Gi.data(), &rank) != 0 || rank == 0)
+      return fail(TEMX_ERANK, "Y0^T Y0 has no positive eigenvalue (N=%lld, K=%d)", (long long)pl->N, K);
+    pl->rank = rank;
+  } else {
+    pl->rank = K;
+  }
   HIPCHK(hipMemcpy(pl->Ginv.p, Gi.data(), Gi.size() * 8, hipMemcpyHostToDevice));
   int zero = 0;
   HIPCHK(hipMemcpy(pl->flag.p, &zero, sizeof(int), hipMemcpyHostToDevice));

@@ -140,11 +140,34 @@ def test_errors_are_loud(eng):
     from pytemdiags_amd._lib import TemxError
     with pytest.raises(TemxError):
         eng.Plan(np.zeros(10), np.linspace(-80, 80, 9), 70)          # L > 63 unsupported
-    with pytest.raises(TemxError):
-        eng.Plan(np.full(200, 12.5), np.linspace(-80, 80, 9), 5)     # rank deficient (one latitude)
     plan = eng.Plan(np.linspace(-89, 89, 300), np.linspace(-80, 80, 9), 5)
     with pytest.raises(TemxError):
         plan.tem_run(*[torch.zeros(300, 4, 1, device="cuda:0", dtype=torch.float64)] * 4)  # set_tem missing
     with pytest.raises(TemxError):
         plan.set_tem(1, 1, np.array([100.0]))
+    plan.close()
+
+
+def test_rank_deficient_grid_uses_pseudo_inverse(eng):
+    """Fewer distinct latitudes than harmonics.  lstsq(Y0, I) is meant to give
+    pinv(Y0) (sph_zonal_mean.py:389), but with duplicated latitudes its eps cut-off lets singular
+    values of ~1e-16 sigma_max through and the reference returns 1e13-sized noise.  The engine
+    falls back from Cholesky to an eigen-decomposition pseudo-inverse of the Gram matrix, i.e. the
+    well-defined minimum-norm operator Y pinv(Y0); compared here with numpy's pinv."""
+    from oracle import tem_oracle as orc
+    rng = np.random.default_rng(7)
+    lats = np.linspace(-75, 75, 12)                      # 12 distinct latitudes, K = 21 harmonics
+    lat = np.repeat(lats, 30) + 0.0
+    rng.shuffle(lat)
+    lat_out = np.linspace(-70, 70, 15)
+    plan = eng.Plan(lat, lat_out, 20)
+    Y0, Y0p = orc.ylm0_matrix(lat, 20), orc.ylm0_matrix(lat_out, 20)
+    Pinv = np.linalg.pinv(Y0, rcond=1e-8)
+    assert np.linalg.matrix_rank(Y0, tol=1e-8) == 12
+    A = rng.standard_normal((lat.size, 4, 3))
+    AA = A.reshape(lat.size, -1)
+    zm = plan.zonal_mean(dev(A)).cpu().numpy().reshape(15, -1)
+    zmn = plan.zonal_mean(dev(A), native=True).cpu().numpy().reshape(lat.size, -1)
+    assert fieldnorm_err(zm, Y0p @ (Pinv @ AA)) <= 1e-9
+    assert fieldnorm_err(zmn, Y0 @ (Pinv @ AA)) <= 1e-9
     plan.close()
