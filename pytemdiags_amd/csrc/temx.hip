@@ -317,7 +317,15 @@ static int launch_recon(temx_plan* pl, int64_t D, const double* C, double* out, 
 // not symmetric.  Pairs are ordered by their northern row so one operand still streams.
 static bool find_mirror_pairs(const double* lat, int64_t N, std::vector<int>& rowN, std::vector<int>& rowS) {
   if (N >= ((int64_t)1 << 31)) return false;
-  const double tol = 1e-12;   // degrees
+  // Two columns pair up when their latitudes are opposite to within `tol` degrees; the pair is then
+  // treated as sitting exactly at +-(northern latitude), which perturbs the operator by
+  // O(L^2 tol).  The default keeps that below the fp64 parity tolerance; TEMX_SYM_TOL_DEG widens
+  // it for grids whose files carry noisier latitudes.
+  double tol = 1e-12;
+  if (const char* e = getenv("TEMX_SYM_TOL_DEG")) {
+    const double t = atof(e);
+    if (t > 0.0 && t < 1e-3) tol = t;
+  }
   std::vector<int> north, south, eq;
   for (int64_t i = 0; i < N; ++i) {
     if (!(std::fabs(lat[i]) <= 90.0 + 1e-9)) return false;

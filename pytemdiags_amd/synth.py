@@ -50,6 +50,16 @@ def cubed_sphere_gll(ne: int):
     P = np.unique(np.round(P, 12), axis=0)
     assert P.shape[0] == ncol_of_ne(ne), (P.shape, ncol_of_ne(ne))
     P /= np.linalg.norm(P, axis=1, keepdims=True)
+    # The ideal grid is mirror symmetric about the equator, but the 12-digit rounding above resolves
+    # the two face-copies of an edge node independently in each hemisphere (1e-12-level asymmetry at
+    # ne240).  Rebuild the south as the exact mirror of the north so latitudes are bitwise +-.
+    north = P[P[:, 2] > 1e-9]
+    eq = P[np.abs(P[:, 2]) <= 1e-9].copy()
+    eq[:, 2] = 0.0
+    eq /= np.linalg.norm(eq, axis=1, keepdims=True)
+    assert 2 * north.shape[0] + eq.shape[0] == P.shape[0]
+    P = np.concatenate([north, north * np.array([1.0, 1.0, -1.0]), eq], axis=0)
+    P = P[np.lexsort((np.round(P[:, 2], 12), np.round(P[:, 1], 12), np.round(P[:, 0], 12)))]
     lat = np.rad2deg(np.arcsin(np.clip(P[:, 2], -1.0, 1.0)))
     lon = np.mod(np.rad2deg(np.arctan2(P[:, 1], P[:, 0])), 360.0)
     return lat, lon
