@@ -87,7 +87,9 @@ int temx_device_count(void);
  * device by the normalised Legendre recurrence, the Gram matrix G = Y0^T Y0 with the MFMA
  * projection kernel, and (unless TEMX_DEFER_FINALIZE) factorises G on the host (Cholesky),
  * which replaces lstsq(Y0, I_N) (sph_zonal_mean.py:389): pinv(Y0) = G^-1 Y0^T.
- * lat_deg_host[ncol], lat_out_deg_host[M] in degrees.  L <= 63 in this version.
+ * lat_deg_host[ncol], lat_out_deg_host[M] in degrees.  L <= 511.  Up to L = 63 (K <= 64) the TEM
+ * sweeps are the fused kernels; larger L runs the same pipeline as 64-harmonic slices (sliced
+ * projections, accumulating native reconstructions, an elementwise eddy-product pass).
  * If every column has a mirror column at the opposite latitude (cubed-sphere, lat-lon, Gaussian
  * grids) the TEM sweeps run in a mirror-paired form that needs ~54 % of the matrix work (same
  * operator, results equal up to rounding); flags & TEMX_NO_SYMMETRY or TEMX_NO_SYM=1 disables it. */

@@ -45,7 +45,7 @@ struct EddyOut {
 // Rows >= N and harmonics >= K are zero, so tails need no masking in the sweeps.
 // rowscale (weights mode, sph_zonal_mean.py:385) scales the blocked copy only.
 // ------------------------------------------------------------------------------------------------
-__global__ void basis_kernel(const double* __restrict__ x, int64_t N, int64_t nrow_pad, int K, int TB,
+__global__ void basis_kernel(const double* __restrict__ x, int64_t N, int64_t nrow_pad, int K, int TB /* blocks stored per group */,
                              const double* __restrict__ norm, const double* __restrict__ rowscale,
                              double* __restrict__ Y0, double* __restrict__ yblk) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -110,6 +110,7 @@ __device__ __forceinline__ bool wg_work(int ndq, int nsplit, int& split, int& dq
 template <typename T, int NF, int NFW, int TB, int PD, int WPS>
 __global__ void __launch_bounds__(256, WPS)
 project_kernel(FieldPtrs<NF> fp, int64_t N, int64_t D, int K, const double* __restrict__ yblk,
+               int gstride /* blocks stored per group */, int tb_off /* first block of this harmonic slice */,
                int64_t nchunk, const double* __restrict__ colscale, int sfield,
                double* __restrict__ partial, int nsplit, int ndt) {
   // NFW fields per wave: a workgroup's 4 waves cover DPW = 4*NFW/NF d-tiles x NF/NFW field groups.
@@ -170,9 +171,20 @@ project_kernel(FieldPtrs<NF> fp, int64_t N, int64_t D, int K, const double* __re
       for (int f = 0; f < NFW; ++f) xn[slot][f][ti] = fb[f][row * D + dcl];
     }
   };
+  // element tid + 256 j of a chunk's staging image = (group gi, block t, element e); in yblk the
+  // groups of a chunk are gstride blocks apart and this slice starts at block tb_off (gstride == TB,
+  // tb_off == 0 when all harmonics fit one slice).  The per-lane offsets are loop invariant.
+  uint32_t yso[YJ];
+#pragma unroll
+  for (int j = 0; j < YJ; ++j) {
+    const int li = tid + 256 * j;
+    const int gi = li / (TB * 16), rem = li % (TB * 16);
+    yso[j] = (uint32_t)((gi < 4 ? gi : 3) * gstride * 16 + tb_off * 16 + rem);
+  }
+  const int64_t ychunk = (int64_t)4 * gstride * 16;
   auto load_ys = [&](int chunk) __attribute__((always_inline)) {   // yblk is padded: never leaves it
 #pragma unroll
-    for (int j = 0; j < YJ; ++j) ys[j] = (yblk + (int64_t)chunk * YE)[tid + 256 * j];
+    for (int j = 0; j < YJ; ++j) ys[j] = (yblk + (int64_t)chunk * ychunk)[yso[j]];
   };
   // one chunk: stage Y0 blocks, barrier, prefetch Y of chunk+1 and X of chunk+PD,
   // 4 groups x TB x NFW MFMAs
@@ -280,15 +292,16 @@ __global__ void __launch_bounds__(256)
 solve_kernel(const double* __restrict__ B, int K, int K4, int M, int64_t D,
              const double* __restrict__ Ginv, const double* __restrict__ Y0p,
              double* __restrict__ C, double* __restrict__ Xb) {
-  __shared__ double sb[64][17];
-  __shared__ double scf[64][17];
+  extern __shared__ double slds[];          // sb[K4][17], scf[K4][17]
+  double* sb = slds;
+  double* scf = slds + (size_t)K4 * 17;
   const int f = blockIdx.y;
   const int64_t d0 = (int64_t)blockIdx.x * 16;
   const int tid = threadIdx.x;
   for (int idx = tid; idx < K * 16; idx += 256) {
     const int k = idx >> 4, dd = idx & 15;
     const int64_t d = d0 + dd;
-    sb[k][dd] = d < D ? B[((int64_t)f * K + k) * D + d] : 0.0;
+    sb[k * 17 + dd] = d < D ? B[((int64_t)f * K + k) * D + d] : 0.0;
   }
   __syncthreads();
   for (int idx = tid; idx < K4 * 16; idx += 256) {
@@ -297,9 +310,9 @@ solve_kernel(const double* __restrict__ B, int K, int K4, int M, int64_t D,
     double v = 0.0;
     if (k < K) {
       const double* gr = Ginv + (int64_t)k * K;
-      for (int kk = 0; kk < K; ++kk) v += gr[kk] * sb[kk][dd];
+      for (int kk = 0; kk < K; ++kk) v += gr[kk] * sb[kk * 17 + dd];
     }
-    scf[k][dd] = v;
+    scf[k * 17 + dd] = v;
     if (C != nullptr && blockIdx.z == 0 && d < D) C[((int64_t)f * K4 + k) * D + d] = v;
   }
   __syncthreads();
@@ -313,7 +326,7 @@ solve_kernel(const double* __restrict__ B, int K, int K4, int M, int64_t D,
       if (d >= D) continue;
       const double* yr = Y0p + (int64_t)m * K;
       double v = 0.0;
-      for (int kk = 0; kk < K; ++kk) v += yr[kk] * scf[kk][dd];
+      for (int kk = 0; kk < K; ++kk) v += yr[kk] * scf[kk * 17 + dd];
       Xb[((int64_t)f * M + m) * D + d] = v;
     }
   }
@@ -535,8 +548,9 @@ eddy_kernel(FieldPtrs<4> fp, int64_t N, int64_t D, int K, const double* __restri
 // sph_zonal_mean.py:285-290, outer matmul with Y = Y0).  Same tile scheme as the eddy sweep.
 template <int TB>
 __global__ void __launch_bounds__(256, 2)
-recon_kernel(int64_t N, int64_t D, const double* __restrict__ yblk, int64_t nchunk,
-             const double* __restrict__ C, double* __restrict__ out, int nsplit, int ndt) {
+recon_kernel(int64_t N, int64_t D, const double* __restrict__ yblk, int gstride, int tb_off, int64_t nchunk,
+             const double* __restrict__ C /* rows of this slice */, double* __restrict__ out, int accumulate,
+             int nsplit, int ndt) {
   extern __shared__ double lds[];
   int split, dq;
   if (!wg_work((ndt + 3) >> 2, nsplit, split, dq)) return;
@@ -552,13 +566,42 @@ recon_kernel(int64_t N, int64_t D, const double* __restrict__ yblk, int64_t nchu
   double* cb = lds + (size_t)wave * (TB * 64) + lane;
 #pragma unroll
   for (int s = 0; s < TB; ++s) cb[s * 64] = C[((int64_t)4 * s + g) * D + dcl];
-  const double* yb = yblk + (lane & 3) * 4 + g;
+  const double* yb = yblk + (int64_t)tb_off * 16 + (lane & 3) * 4 + g;
   for (int64_t group = c0; group < c1; ++group) {
     double rec = 0.0;
 #pragma unroll
-    for (int s = 0; s < TB; ++s) rec = TEMX_MFMA4(yb[(group * TB + s) * 16], cb[s * 64], rec);
+    for (int s = 0; s < TB; ++s) rec = TEMX_MFMA4(yb[(group * gstride + s) * 16], cb[s * 64], rec);
     const int64_t row = group * 4 + g;
-    if (dvalid && row < N) out[row * D + d] = rec;
+    if (dvalid && row < N) {
+      if (accumulate) rec += out[row * D + d];
+      out[row * D + d] = rec;
+    }
+  }
+}
+
+// eddies and eddy products from stored native-grid means (large-L path, where the harmonics do not
+// fit one fused sweep):  e_f = x_f - xbar_f (theta scaled), p = u'v', u'w', v'theta'.
+// eo.p[0..3] eddies, eo.p[4..6] products; NULL entries are skipped.
+template <typename T>
+__global__ void __launch_bounds__(256)
+eddy_from_xbar_kernel(FieldPtrs<4> fp, FieldPtrs<4> xbar /* native zonal means, [N][D] doubles each */,
+                      int64_t N, int64_t D, const double* __restrict__ colscale, EddyOut eo) {
+  const int64_t total = N * D;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    double e[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      double x = (double)reinterpret_cast<const T*>(fp.p[f])[idx];
+      if (f == 2 && colscale != nullptr) x *= colscale[idx % D];
+      e[f] = x - reinterpret_cast<const double*>(xbar.p[f])[idx];
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+      if (eo.p[f]) eo.p[f][idx] = e[f];
+    if (eo.p[4]) eo.p[4][idx] = e[0] * e[1];
+    if (eo.p[5]) eo.p[5][idx] = e[0] * e[3];
+    if (eo.p[6]) eo.p[6][idx] = e[1] * e[2];
   }
 }
 

@@ -80,6 +80,10 @@ struct temx_plan {
   int device = 0, num_cu = 256;
   int64_t N = 0, nchunk = 0;
   int L = 0, K = 0, TB = 0, K4 = 0, M = 0;
+  // harmonics beyond one fused sweep (K > 64): slices of 16 blocks, `stride` blocks stored per group
+  int stride = 0, nslice = 1;
+  bool large = false;
+  DevBuf Bs, XB, P3;             // large-L path: slice sums, native means [4][N][D], products [3][N][D]
   bool finalized = false;
   int rank = 0;               // numerical rank of Y0 (== K unless the pseudo-inverse fallback ran)
   DevBuf x, Y0, yblk, yblk_w, Y0p, G, Ginv, norm, flag;
@@ -191,12 +195,13 @@ static int proj_wps(int NF, int dpw) {
 
 template <typename T, int NF, typename Cfg>
 static int launch_project_c(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t D, const double* colscale,
-                            int sfield, double* partial, const Split& sp, hipStream_t st) {
+                            int sfield, double* partial, const Split& sp, hipStream_t st, int tb_off,
+                            int Kloc) {
   dim3 grid(sp.grid), block(256);
 #define TEMX_LP(TBv)                                                                                  \
   hipLaunchKernelGGL((project_kernel<T, NF, Cfg::NFW, TBv, Cfg::PD, Cfg::WPS>), grid, block, 0, st, fp, \
-                     pl->N, D, pl->K, pl->yproj_ptr(), pl->nchunk, colscale, sfield, partial,         \
-                     sp.nsplit, sp.ndt)
+                     pl->N, D, Kloc, pl->yproj_ptr(), pl->stride, tb_off, pl->nchunk, colscale,       \
+                     sfield, partial, sp.nsplit, sp.ndt)
   switch (pl->TB) {
     case 4: TEMX_LP(4); break;
     case 8: TEMX_LP(8); break;
@@ -208,23 +213,32 @@ static int launch_project_c(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t D, c
   return TEMX_OK;
 }
 
+struct ProjCfg3 { static constexpr int NFW = 3, PD = 1, WPS = 2; };   // the 3 eddy products (large-L path)
+
 template <typename T, int NF>
 static int launch_project_t(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t D, const double* colscale,
-                            int sfield, double* partial, const Split& sp, hipStream_t st) {
+                            int sfield, double* partial, const Split& sp, hipStream_t st, int tb_off,
+                            int Kloc) {
   if constexpr (NF == 1) {
-    return launch_project_c<T, NF, ProjCfg1>(pl, fp, D, colscale, sfield, partial, sp, st);
+    return launch_project_c<T, NF, ProjCfg1>(pl, fp, D, colscale, sfield, partial, sp, st, tb_off, Kloc);
+  } else if constexpr (NF == 3) {
+    return launch_project_c<T, NF, ProjCfg3>(pl, fp, D, colscale, sfield, partial, sp, st, tb_off, Kloc);
   } else {
-    if (sp.dpw == 1) return launch_project_c<T, NF, ProjCfgE>(pl, fp, D, colscale, sfield, partial, sp, st);
-    return launch_project_c<T, NF, ProjCfgC>(pl, fp, D, colscale, sfield, partial, sp, st);
+    if (sp.dpw == 1)
+      return launch_project_c<T, NF, ProjCfgE>(pl, fp, D, colscale, sfield, partial, sp, st, tb_off, Kloc);
+    return launch_project_c<T, NF, ProjCfgC>(pl, fp, D, colscale, sfield, partial, sp, st, tb_off, Kloc);
   }
 }
 
 template <int NF>
 static int launch_project(temx_plan* pl, const FieldPtrs<NF>& fp, int dtype, int64_t D,
                           const double* colscale, int sfield, double* partial, const Split& sp,
-                          hipStream_t st) {
-  if (dtype == TEMX_F64) return launch_project_t<double, NF>(pl, fp, D, colscale, sfield, partial, sp, st);
-  if (dtype == TEMX_F32) return launch_project_t<float, NF>(pl, fp, D, colscale, sfield, partial, sp, st);
+                          hipStream_t st, int tb_off = 0, int Kloc = -1) {
+  if (Kloc < 0) Kloc = pl->K;
+  if (dtype == TEMX_F64)
+    return launch_project_t<double, NF>(pl, fp, D, colscale, sfield, partial, sp, st, tb_off, Kloc);
+  if (dtype == TEMX_F32)
+    return launch_project_t<float, NF>(pl, fp, D, colscale, sfield, partial, sp, st, tb_off, Kloc);
   return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
 }
 
@@ -243,7 +257,14 @@ static int launch_solve(temx_plan* pl, const double* B, int NF, int64_t D, doubl
   const int64_t base = ((D + 15) / 16) * NF;
   int ms = Xb ? (int)std::min<int64_t>(12, std::max<int64_t>(1, (2 * pl->num_cu + base - 1) / base)) : 1;
   dim3 grid((unsigned)((D + 15) / 16), NF, ms);
-  hipLaunchKernelGGL(solve_kernel, grid, dim3(256), 0, st, B, pl->K, pl->K4, pl->M, D, pl->Ginv.d(),
+  const size_t slds = (size_t)2 * pl->K4 * 17 * sizeof(double);
+  static bool solve_attr = false;
+  if (!solve_attr && slds > 48 * 1024) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    solve_attr = true;
+  }
+  hipLaunchKernelGGL(solve_kernel, grid, dim3(256), slds, st, B, pl->K, pl->K4, pl->M, D, pl->Ginv.d(),
                      pl->Y0p.d(), C, Xb);
   HIPCHK(hipGetLastError());
   return TEMX_OK;
@@ -291,23 +312,49 @@ static int launch_eddy_t(temx_plan* pl, const FieldPtrs<4>& fp, const double* C,
 static int launch_recon(temx_plan* pl, int64_t D, const double* C, double* out, hipStream_t st) {
   Split sp = choose_split(D, pl->nchunk, 2 * pl->num_cu);
   dim3 grid(sp.grid), block(256);
-#define TEMX_LR(TBv)                                                                                  \
+#define TEMX_LR(TBv, tboff, Cs, acc)                                                                  \
   do {                                                                                                \
     auto kern = recon_kernel<TBv>;                                                                    \
     const size_t lds = (size_t)4 * TBv * 64 * sizeof(double);                                         \
-    hipLaunchKernelGGL(kern, grid, block, lds, st, pl->N, D, pl->yblk.d(), pl->nchunk, C, out,        \
-                       sp.nsplit, sp.ndt);                                                            \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, pl->N, D, pl->yblk.d(), pl->stride, tboff,         \
+                       pl->nchunk, Cs, out, acc, sp.nsplit, sp.ndt);                                  \
   } while (0)
-  switch (pl->TB) {
-    case 4: TEMX_LR(4); break;
-    case 8: TEMX_LR(8); break;
-    case 13: TEMX_LR(13); break;
-    default: TEMX_LR(16); break;
+  if (pl->large) {   // one pass per slice of 64 harmonics, accumulating into out
+    for (int sl = 0; sl < pl->nslice; ++sl) TEMX_LR(16, 16 * sl, C + (int64_t)64 * sl * D, sl > 0 ? 1 : 0);
+  } else {
+    switch (pl->TB) {
+      case 4: TEMX_LR(4, 0, C, 0); break;
+      case 8: TEMX_LR(8, 0, C, 0); break;
+      case 13: TEMX_LR(13, 0, C, 0); break;
+      default: TEMX_LR(16, 0, C, 0); break;
+    }
   }
 #undef TEMX_LR
   HIPCHK(hipGetLastError());
   return TEMX_OK;
 }
+
+// B[NF][K][D] = Y0^T {fields}: one projection sweep, or one per slice of 64 harmonics (large L)
+template <int NF>
+static int project_all(temx_plan* pl, const FieldPtrs<NF>& fp, int dtype, int64_t D, const double* colscale,
+                       int sfield, const Split& sp, double* B, hipStream_t st) {
+  int rc;
+  if (!pl->large) {
+    if ((rc = launch_project<NF>(pl, fp, dtype, D, colscale, sfield, pl->partial.d(), sp, st))) return rc;
+    return launch_reduce(pl, pl->partial.d(), sp.nsplit, (int64_t)NF * pl->K * D, B, st);
+  }
+  if ((rc = pl->Bs.ensure((size_t)NF * 64 * D * 8))) return rc;
+  for (int sl = 0; sl < pl->nslice; ++sl) {
+    const int Ks = std::min(64, pl->K - 64 * sl);
+    if ((rc = launch_project<NF>(pl, fp, dtype, D, colscale, sfield, pl->partial.d(), sp, st, 16 * sl, Ks))) return rc;
+    if ((rc = launch_reduce(pl, pl->partial.d(), sp.nsplit, (int64_t)NF * Ks * D, pl->Bs.d(), st))) return rc;
+    for (int f = 0; f < NF; ++f)
+      HIPCHK(hipMemcpyAsync(B + ((int64_t)f * pl->K + 64 * sl) * D, pl->Bs.d() + (int64_t)f * Ks * D,
+                            (size_t)Ks * D * 8, hipMemcpyDeviceToDevice, st));
+  }
+  return TEMX_OK;
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // mirror pairing of an equatorially symmetric grid (kernels_sym.hpp)
@@ -598,7 +645,7 @@ void temx_plan_destroy(temx_plan* pl) {
   DevBuf* bufs[] = {&pl->x, &pl->Y0, &pl->yblk, &pl->yblk_w, &pl->Y0p, &pl->G, &pl->Ginv, &pl->norm,
                     &pl->flag, &pl->p, &pl->pg, &pl->lg, &pl->coslat, &pl->fcor, &pl->colscale,
                     &pl->B4, &pl->B3, &pl->C4, &pl->zb, &pl->partial, &pl->opB, &pl->opC,
-                    &pl->Bq, &pl->Bq2, &pl->Ct, &pl->tz, &pl->rows, &pl->ysym};
+                    &pl->Bq, &pl->Bq2, &pl->Ct, &pl->tz, &pl->rows, &pl->ysym, &pl->Bs, &pl->XB, &pl->P3};
   for (DevBuf* b : bufs) b->release();
   for (int w = 0; w < 2; ++w)
     for (auto& tl : pl->timed[w]) {
@@ -611,7 +658,7 @@ void temx_plan_destroy(temx_plan* pl) {
 static int build_basis(temx_plan* pl, const double* rowscale_dev, double* Y0, double* yblk) {
   const int64_t npad = pl->nchunk * 16;
   hipLaunchKernelGGL(basis_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, 0, pl->x.d(), pl->N,
-                     npad, pl->K, pl->TB, pl->norm.d(), rowscale_dev, Y0, yblk);
+                     npad, pl->K, pl->stride, pl->norm.d(), rowscale_dev, Y0, yblk);
   HIPCHK(hipGetLastError());
   return TEMX_OK;
 }
@@ -621,7 +668,7 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
   if (!out || !lat_deg_host || !lat_out_deg_host) return fail(TEMX_EINVAL, "null argument");
   *out = nullptr;
   if (ncol < 1 || M < 1 || L < 0) return fail(TEMX_EINVAL, "ncol, M must be >= 1 and L >= 0");
-  if (L > 63) return fail(TEMX_EUNSUPPORTED, "L = %d: this version supports L <= 63", L);
+  if (L > 511) return fail(TEMX_EUNSUPPORTED, "L = %d: this version supports L <= 511", L);
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail(TEMX_EHIP, "device %d not available (%d visible)", device, ndev);
@@ -640,7 +687,13 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
   pl->K = L + 1;
   // l-blocks of 4 harmonics per row; the sweeps are instantiated for TB in {4, 8, 13, 16}
   pl->TB = pl->K <= 16 ? 4 : (pl->K <= 32 ? 8 : (pl->K <= 52 ? 13 : 16));
-  pl->K4 = 4 * pl->TB;
+  pl->stride = pl->TB;
+  if (pl->K > 64) {   // several slices of 64 harmonics: sliced sweeps instead of the fused ones
+    pl->large = true;
+    pl->nslice = (pl->K + 63) / 64;
+    pl->stride = 16 * pl->nslice;
+  }
+  pl->K4 = 4 * pl->stride;
   pl->M = M;
   pl->lat_out_deg.assign(lat_out_deg_host, lat_out_deg_host + M);
   int rc = TEMX_OK;
@@ -654,15 +707,15 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
   std::vector<double> xs((size_t)std::max<int64_t>(ncol, M));
   for (int64_t i = 0; i < ncol; ++i) xs[i] = std::cos((90.0 - lat_deg_host[i]) * d2r);
   if ((rc = upload(pl->x, xs.data(), (size_t)ncol * 8))) return bail(rc);
-  std::vector<double> norm(64, 0.0);
+  std::vector<double> norm((size_t)std::max(64, pl->K4), 0.0);
   for (int l = 0; l < pl->K; ++l) norm[l] = std::sqrt((2.0 * l + 1.0) / (4.0 * M_PI));
-  if ((rc = upload(pl->norm, norm.data(), 64 * 8))) return bail(rc);
+  if ((rc = upload(pl->norm, norm.data(), norm.size() * 8))) return bail(rc);
   int zero = 0;
   if ((rc = upload(pl->flag, &zero, sizeof(int)))) return bail(rc);
 
   if ((rc = pl->Y0.ensure((size_t)ncol * pl->K * 8))) return bail(rc);
   // one extra chunk of blocks: the sweeps prefetch A operands one group / step ahead
-  if ((rc = pl->yblk.ensure((size_t)(pl->nchunk + 1) * 4 * pl->TB * 16 * 8))) return bail(rc);
+  if ((rc = pl->yblk.ensure((size_t)(pl->nchunk + 1) * 4 * pl->stride * 16 * 8))) return bail(rc);
   HIPCHK(hipMemset(pl->yblk.p, 0, pl->yblk.bytes));
   if ((rc = build_basis(pl, nullptr, pl->Y0.d(), pl->yblk.d()))) return bail(rc);
 
@@ -677,7 +730,7 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
     }
     const int64_t mch = (M + 15) / 16;
     hipLaunchKernelGGL(basis_kernel, dim3((unsigned)((mch * 16 + 255) / 256)), dim3(256), 0, 0, xo.d(),
-                       (int64_t)M, mch * 16, pl->K, pl->TB, pl->norm.d(), (const double*)nullptr,
+                       (int64_t)M, mch * 16, pl->K, pl->stride, pl->norm.d(), (const double*)nullptr,
                        pl->Y0p.d(), (double*)nullptr);
     hipError_t e = hipDeviceSynchronize();
     xo.release();
@@ -689,11 +742,10 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
     if ((rc = pl->G.ensure((size_t)pl->K * pl->K * 8))) return bail(rc);
     if ((rc = pl->Ginv.ensure((size_t)pl->K * pl->K * 8))) return bail(rc);
     Split sp = choose_split(pl->K, pl->nchunk, 2 * pl->num_cu);
-    if ((rc = pl->partial.ensure((size_t)sp.nsplit * pl->K * pl->K * 8))) return bail(rc);
+    if ((rc = pl->partial.ensure((size_t)sp.nsplit * std::min(pl->K, 64) * pl->K * 8))) return bail(rc);
     FieldPtrs<1> fp;
     fp.p[0] = pl->Y0.p;
-    if ((rc = launch_project<1>(pl, fp, TEMX_F64, pl->K, nullptr, -1, pl->partial.d(), sp, 0))) return bail(rc);
-    if ((rc = launch_reduce(pl, pl->partial.d(), sp.nsplit, (int64_t)pl->K * pl->K, pl->G.d(), 0))) return bail(rc);
+    if ((rc = project_all<1>(pl, fp, TEMX_F64, pl->K, nullptr, -1, sp, pl->G.d(), 0))) return bail(rc);
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return bail(fail(TEMX_EHIP, "gram kernel failed: %s", hipGetErrorString(e)));
   }
@@ -701,7 +753,7 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
   {
     const char* e = getenv("TEMX_NO_SYM");
     std::vector<int> rN, rS;
-    if (!(flags & TEMX_NO_SYMMETRY) && !(e && e[0] == '1') && find_mirror_pairs(lat_deg_host, ncol, rN, rS)) {
+    if (!pl->large && !(flags & TEMX_NO_SYMMETRY) && !(e && e[0] == '1') && find_mirror_pairs(lat_deg_host, ncol, rN, rS)) {
       const int nhalf = (pl->K + 1) / 2;                       // even harmonics (>= odd ones)
       const int tbs = (nhalf + 3) / 4;
       pl->TBS = tbs <= 2 ? 2 : (tbs <= 4 ? 4 : (tbs <= 7 ? 7 : 8));
@@ -827,12 +879,11 @@ int temx_project(temx_plan* pl, const void* A, int dtype, int64_t D, double* B, 
   if (D < 1 || D >= ((int64_t)1 << 28)) return fail(TEMX_EINVAL, "D must be in [1, 2^28)");
   HIPCHK(hipSetDevice(pl->device));
   Split sp = choose_split(D, pl->nchunk, 2 * pl->num_cu);
-  int rc = pl->partial.ensure((size_t)sp.nsplit * pl->K * D * 8);
+  int rc = pl->partial.ensure((size_t)sp.nsplit * std::min(pl->K, 64) * D * 8);
   if (rc) return rc;
   FieldPtrs<1> fp;
   fp.p[0] = A;
-  if ((rc = launch_project<1>(pl, fp, dtype, D, nullptr, -1, pl->partial.d(), sp, S_(stream)))) return rc;
-  return launch_reduce(pl, pl->partial.d(), sp.nsplit, (int64_t)pl->K * D, B, S_(stream));
+  return project_all<1>(pl, fp, dtype, D, nullptr, -1, sp, B, S_(stream));
 }
 
 int temx_zonal_mean_from_sums(temx_plan* pl, const double* B, int64_t D, double* out, int native,
@@ -914,6 +965,10 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
   if ((rc = pl->C4.ensure((size_t)4 * pl->K4 * D * 8))) return rc;
   if ((rc = pl->zb.ensure((size_t)8 * M * D * 8))) return rc;
   pl->sp_proj1 = choose_split(D, pl->nchunk, 2 * pl->num_cu);
+  if (pl->large) {   // products are projected three at a time, 64 harmonics per pass
+    const size_t need3 = (size_t)pl->sp_proj1.nsplit * 3 * 64 * D * 8;
+    if ((rc = pl->partial.ensure(std::max(need3, pl->partial.bytes)))) return rc;
+  }
   if (pl->sym) {
     const int64_t nch = (pl->npg + SYM_PROJ_CH - 1) / SYM_PROJ_CH;
     pl->sp_sproj4 = Split();
@@ -947,6 +1002,7 @@ int temx_tem_stage1(temx_plan* pl, const void* ua, const void* va, const void* t
   hipStream_t st = S_(stream);
   FieldPtrs<4> fp;
   fp.p[0] = ua; fp.p[1] = va; fp.p[2] = ta; fp.p[3] = wap;
+  if (pl->large) return project_all<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->sp_proj4, B4, st);
   TimedLaunch tl{};
   time_begin(pl, 0, st, tl);
   const bool sp4 = sym_project(pl, 4);
@@ -958,6 +1014,57 @@ int temx_tem_stage1(temx_plan* pl, const void* ua, const void* va, const void* t
                        (int64_t)4 * pl->K * pl->D, B4, st);
 }
 
+// ---- large-L (K > 64) second sweep: the fused eddy kernel keeps all coefficients of a d-tile in LDS,
+// which stops at 64 harmonics.  Here the native zonal means are materialised by accumulating
+// reconstruction passes (64 harmonics each), the eddies/products by one elementwise kernel, and
+// the products are projected slice by slice.  ~8x the HBM traffic of the fused path; correct for
+// any L <= 511.
+static int large_ws(temx_plan* pl) {
+  const size_t nd = (size_t)pl->N * pl->D * 8;
+  int rc;
+  if ((rc = pl->XB.ensure(5 * nd))) return rc;     // ub vb thetab wapb (+ qb for tracers), native
+  return pl->P3.ensure(3 * nd);
+}
+
+static int launch_eddy_from_xbar(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, const FieldPtrs<4>& xb,
+                                 const double* colscale, const EddyOut& eo, hipStream_t st) {
+  dim3 grid((unsigned)(pl->num_cu * 8)), block(256);
+  if (dtype == TEMX_F64)
+    hipLaunchKernelGGL(eddy_from_xbar_kernel<double>, grid, block, 0, st, fp, xb, pl->N, pl->D, colscale, eo);
+  else if (dtype == TEMX_F32)
+    hipLaunchKernelGGL(eddy_from_xbar_kernel<float>, grid, block, 0, st, fp, xb, pl->N, pl->D, colscale, eo);
+  else
+    return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+static FieldPtrs<4> native_means(temx_plan* pl, int a, int b, int c, int d) {
+  const int64_t nd = pl->N * pl->D;
+  FieldPtrs<4> xb;
+  xb.p[0] = pl->XB.d() + a * nd; xb.p[1] = pl->XB.d() + b * nd;
+  xb.p[2] = pl->XB.d() + c * nd; xb.p[3] = pl->XB.d() + d * nd;
+  return xb;
+}
+
+static int tem_stage2_large(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, const double* B4, double* B3,
+                            hipStream_t st) {
+  int rc;
+  if ((rc = large_ws(pl))) return rc;
+  const int64_t nd = pl->N * pl->D;
+  if ((rc = launch_solve(pl, B4, 4, pl->D, pl->C4.d(), pl->zb.d(), st))) return rc;
+  for (int f = 0; f < 4; ++f)
+    if ((rc = launch_recon(pl, pl->D, pl->C4.d() + (int64_t)f * pl->K4 * pl->D, pl->XB.d() + f * nd, st))) return rc;
+  EddyOut eo{};
+  FieldPtrs<3> f3;
+  for (int i = 0; i < 3; ++i) {
+    eo.p[4 + i] = pl->P3.d() + i * nd;
+    f3.p[i] = eo.p[4 + i];
+  }
+  if ((rc = launch_eddy_from_xbar(pl, fp, dtype, native_means(pl, 0, 1, 2, 3), pl->colscale.d(), eo, st))) return rc;
+  return project_all<3>(pl, f3, TEMX_F64, pl->D, nullptr, -1, pl->sp_proj1, B3, st);
+}
+
 int temx_tem_stage2(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap,
                     int dtype, const double* B4, double* B3, void* stream) {
   int rc = tem_ready(pl);
@@ -965,6 +1072,7 @@ int temx_tem_stage2(temx_plan* pl, const void* ua, const void* va, const void* t
   if (!ua || !va || !ta || !wap || !B4 || !B3) return fail(TEMX_EINVAL, "null argument");
   HIPCHK(hipSetDevice(pl->device));
   hipStream_t st = S_(stream);
+  if (pl->large) return tem_stage2_large(pl, four(ua, va, ta, wap), dtype, B4, B3, st);
   // C = G^-1 B4 and the four zonal means ub vb thetab wapb -> zb[0..3]
   if ((rc = launch_solve(pl, B4, 4, pl->D, pl->C4.d(), pl->zb.d(), st))) return rc;
   TimedLaunch tl{};
@@ -1013,6 +1121,11 @@ int temx_tem_eddy(temx_plan* pl, const void* ua, const void* va, const void* ta,
   HIPCHK(hipSetDevice(pl->device));
   EddyOut eo;
   for (int i = 0; i < TEMX_NEDDY; ++i) eo.p[i] = eddy_ptrs_host[i];
+  if (pl->large) {
+    if (!pl->XB.p) return fail(TEMX_ESTATE, "temx_tem_stage2 has not been called");
+    return launch_eddy_from_xbar(pl, four(ua, va, ta, wap), dtype, native_means(pl, 0, 1, 2, 3),
+                                 pl->colscale.d(), eo, S_(stream));
+  }
   return run_eddy<0>(pl, four(ua, va, ta, wap), dtype, pl->C4.d(), nullptr, &eo, S_(stream));
 }
 
@@ -1036,6 +1149,7 @@ int temx_tracer_stage1(temx_plan* pl, const void* q, int dtype, double* Bq, void
   if ((rc = tracer_ws(pl))) return rc;
   FieldPtrs<1> fp;
   fp.p[0] = q;
+  if (pl->large) return project_all<1>(pl, fp, dtype, pl->D, nullptr, -1, pl->sp_proj1, Bq, S_(stream));
   const bool sp1 = sym_project(pl, 1);
   rc = sp1 ? launch_project_sym<1>(pl, fp, dtype, pl->D, nullptr, -1, pl->partial.d(), pl->sp_sproj1, S_(stream))
            : launch_project<1>(pl, fp, dtype, pl->D, nullptr, -1, pl->partial.d(), pl->sp_proj1, S_(stream));
@@ -1055,6 +1169,23 @@ int temx_tracer_stage2(temx_plan* pl, const void* q, const void* va, const void*
   const size_t slab = (size_t)pl->K4 * pl->D * 8;
   // coefficients: Ct = (C_q, C_v, C_w); qb -> tz[0]
   if ((rc = launch_solve(pl, Bq, 1, pl->D, pl->Ct.d(), pl->tz.d(), st))) return rc;
+  if (pl->large) {   // q' v' and q' omega' from the native means of the last temx_tem_stage2
+    if (!pl->XB.p) return fail(TEMX_ESTATE, "temx_tem_stage2 has not been called");
+    const int64_t nd = pl->N * pl->D;
+    if ((rc = launch_recon(pl, pl->D, pl->Ct.d(), pl->XB.d() + 4 * nd, st))) return rc;
+    EddyOut eo{};
+    eo.p[4] = pl->P3.d();
+    eo.p[5] = pl->P3.d() + nd;
+    if ((rc = launch_eddy_from_xbar(pl, four(q, va, va, wap), dtype, native_means(pl, 4, 1, 1, 3), nullptr, eo, st)))
+      return rc;
+    for (int i = 0; i < 2; ++i) {
+      FieldPtrs<1> f1;
+      f1.p[0] = eo.p[4 + i];
+      if ((rc = project_all<1>(pl, f1, TEMX_F64, pl->D, nullptr, -1, pl->sp_proj1, Bq2 + (int64_t)i * pl->K * pl->D, st)))
+        return rc;
+    }
+    return TEMX_OK;
+  }
   HIPCHK(hipMemcpyAsync((char*)pl->Ct.p + slab, (char*)pl->C4.p + slab, slab, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpyAsync((char*)pl->Ct.p + 2 * slab, (char*)pl->C4.p + 3 * slab, slab, hipMemcpyDeviceToDevice, st));
   if ((rc = run_eddy<1>(pl, four(q, va, wap, nullptr), dtype, pl->Ct.d(), pl->partial.d(), nullptr, st))) return rc;
@@ -1098,6 +1229,9 @@ int temx_tracer_eddy(temx_plan* pl, const void* q, const void* va, const void* w
   eo.p[0] = ptrs3_host[0];
   eo.p[4] = ptrs3_host[1];
   eo.p[5] = ptrs3_host[2];
+  if (pl->large)
+    return launch_eddy_from_xbar(pl, four(q, va, va, wap), dtype, native_means(pl, 4, 1, 1, 3), nullptr, eo,
+                                 S_(stream));
   return run_eddy<1>(pl, four(q, va, wap, nullptr), dtype, pl->Ct.d(), nullptr, &eo, S_(stream));
 }
 

@@ -87,7 +87,7 @@ def test_two_ranks_on_one_gpu(mode):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert paired and not bad
+    assert paired == (os.environ.get("TEMX_NO_SYM") != "1") and not bad
     # unsharded reference run in this process
     plan = engine.Plan(lat, lat_zm, 50)
     plan.set_tem(NLEV, NT, plev * 100)

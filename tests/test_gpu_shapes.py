@@ -42,6 +42,8 @@ def run_case(ne, nlev, nt, L=50, dtype=np.float64, seed=0):
     (8, 12, 2, 31),     # TB = 8
     (8, 12, 2, 60),     # TB = 16
     (16, 24, 3, 50),    # D = 72 again with more columns per split
+    (16, 10, 3, 80),    # K = 81 > 64: sliced large-L path, 2 slices
+    (16, 6, 2, 130),    # K = 131: 3 slices, ragged last slice
 ])
 def test_pipeline_shapes_fp64(ne, nlev, nt, L):
     run_case(ne, nlev, nt, L)
@@ -189,7 +191,9 @@ def test_ncol_sharded_flow_emulated_on_one_gpu(symmetric_shards):
     else:
         parts = [np.arange(*sharding.shard_bounds(lat.size, 2, r)) for r in range(2)]
     plans = [engine.Plan(lat[p], lat_zm, 50, defer_finalize=True) for p in parts]
-    assert [pl.paired for pl in plans] == [symmetric_shards] * 2
+    import os
+    nosym = os.environ.get("TEMX_NO_SYM") == "1"
+    assert [pl.paired for pl in plans] == [symmetric_shards and not nosym] * 2
     G = sum(pl.matrix(_lib.MAT_GRAM) for pl in plans)                   # all-reduce (i)
     loc = []
     for pl, p in zip(plans, parts):
@@ -211,3 +215,36 @@ def test_ncol_sharded_flow_emulated_on_one_gpu(symmetric_shards):
     assert not any(pl.status() for pl in plans)
     for pl in plans + [full]:
         pl.close()
+
+
+def test_large_L_eddies_and_tracer_vs_oracle():
+    """K > 64 (sliced sweeps): native eddies/products and the tracer TEM against the oracle."""
+    from oracle import tem_oracle as orc
+    from pytemdiags_amd import _lib, engine, synth
+    ne, nlev, nt, L = 12, 9, 2, 70
+    lat, lon = synth.cubed_sphere_gll(ne)
+    plev = synth.pressure_levels(nlev)
+    f = synth.analytic_fields(lat, lon, plev, nt, seed=3)
+    q = synth.analytic_tracer(lat, lon, plev, nt, which=1)
+    ref = orc.TEMOracle(*f, lat, plev, L=L, mode="factorised", q=[q])
+    plan = engine.Plan(lat, ref.lat, L)
+    assert not plan.paired                                  # the paired sweeps stop at 64 harmonics
+    plan.set_tem(nlev, nt, plev * 100)
+    d = [torch.as_tensor(x, device="cuda:0") for x in f]
+    qd = torch.as_tensor(q, device="cuda:0")
+    res, _ = plan.tem_run(*d)
+    ed = plan.tem_eddy(*d)
+    for n in _lib.EDDY_NAMES:
+        assert fieldnorm_err(ed[n].cpu().numpy(), getattr(ref, n)) <= 1e-10, n
+    tres, tzon = plan.tracer_run(qd, d[1], d[3], want_zonal=True)
+    assert not plan.status()
+    for i, n in enumerate(_lib.TRACER_RESULT_NAMES):
+        e = fieldnorm_err(tres[i].cpu().numpy(), getattr(ref, n)(0))
+        assert e <= 1e-10, (n, e)
+    for i, n in enumerate(_lib.TRACER_ZONAL_NAMES):
+        e = fieldnorm_err(tzon[i].cpu().numpy(), getattr(ref, n)[0])
+        assert e <= 1e-10, (n, e)
+    te = plan.tracer_eddy(qd, d[1], d[3])
+    for n in _lib.TRACER_EDDY_NAMES:
+        assert fieldnorm_err(te[n].cpu().numpy(), getattr(ref, n)[0]) <= 1e-10, n
+    plan.close()
