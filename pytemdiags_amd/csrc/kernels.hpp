@@ -288,46 +288,73 @@ reduce_partials_kernel(const double* __restrict__ partial, int nsplit, int64_t n
 // K x 16 coefficients (cheap) so that small problems still fill the chip.  C is stored with
 // K4 = 4*TB rows (rows >= K zero) by slice 0.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+// STAGE = true (K <= 64): Ginv and this block's Y0p rows are staged in LDS together with the B tile,
+// so the kernel has a single global round trip before its arithmetic (it is latency, not
+// throughput, that matters here: the whole solve is a few hundred KB).
+template <bool STAGE>
+__global__ void __launch_bounds__(1024)
 solve_kernel(const double* __restrict__ B, int K, int K4, int M, int64_t D,
              const double* __restrict__ Ginv, const double* __restrict__ Y0p,
              double* __restrict__ C, double* __restrict__ Xb) {
-  extern __shared__ double slds[];          // sb[K4][17], scf[K4][17]
+  extern __shared__ double slds[];          // sb[K4][17], scf[K4][17], (STAGE) sg[K][K], sy[mper][K]
   double* sb = slds;
   double* scf = slds + (size_t)K4 * 17;
+  double* sg = scf + (size_t)K4 * 17;
+  double* sy = sg + (STAGE ? K * K : 0);
   const int f = blockIdx.y;
   const int64_t d0 = (int64_t)blockIdx.x * 16;
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < K * 16; idx += 256) {
+  const int mper = (M + gridDim.z - 1) / gridDim.z;
+  const int m0 = blockIdx.z * mper;
+  const int m1 = m0 + mper < M ? m0 + mper : M;
+  for (int idx = tid; idx < K * 16; idx += 1024) {
     const int k = idx >> 4, dd = idx & 15;
     const int64_t d = d0 + dd;
     sb[k * 17 + dd] = d < D ? B[((int64_t)f * K + k) * D + d] : 0.0;
   }
+  if (STAGE) {
+    for (int idx = tid; idx < K * K; idx += 1024) sg[idx] = Ginv[idx];
+    if (Xb != nullptr)
+      for (int idx = tid; idx < (m1 - m0) * K; idx += 1024) sy[idx] = Y0p[(int64_t)m0 * K + idx];
+  }
   __syncthreads();
-  for (int idx = tid; idx < K4 * 16; idx += 256) {
+  for (int idx = tid; idx < K4 * 16; idx += 1024) {
     const int k = idx >> 4, dd = idx & 15;
     const int64_t d = d0 + dd;
     double v = 0.0;
     if (k < K) {
-      const double* gr = Ginv + (int64_t)k * K;
-      for (int kk = 0; kk < K; ++kk) v += gr[kk] * sb[kk * 17 + dd];
+      const double* gr = STAGE ? sg + k * K : Ginv + (int64_t)k * K;
+      double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;      // four chains: the dot is latency bound
+      int kk = 0;
+      for (; kk + 4 <= K; kk += 4) {
+        v0 += gr[kk] * sb[kk * 17 + dd];
+        v1 += gr[kk + 1] * sb[(kk + 1) * 17 + dd];
+        v2 += gr[kk + 2] * sb[(kk + 2) * 17 + dd];
+        v3 += gr[kk + 3] * sb[(kk + 3) * 17 + dd];
+      }
+      for (; kk < K; ++kk) v0 += gr[kk] * sb[kk * 17 + dd];
+      v = (v0 + v1) + (v2 + v3);
     }
     scf[k * 17 + dd] = v;
     if (C != nullptr && blockIdx.z == 0 && d < D) C[((int64_t)f * K4 + k) * D + d] = v;
   }
   __syncthreads();
   if (Xb != nullptr) {
-    const int mper = (M + gridDim.z - 1) / gridDim.z;
-    const int m0 = blockIdx.z * mper;
-    const int m1 = m0 + mper < M ? m0 + mper : M;
-    for (int idx = tid; idx < (m1 - m0) * 16; idx += 256) {
+    for (int idx = tid; idx < (m1 - m0) * 16; idx += 1024) {
       const int m = m0 + (idx >> 4), dd = idx & 15;
       const int64_t d = d0 + dd;
       if (d >= D) continue;
-      const double* yr = Y0p + (int64_t)m * K;
-      double v = 0.0;
-      for (int kk = 0; kk < K; ++kk) v += yr[kk] * scf[kk * 17 + dd];
-      Xb[((int64_t)f * M + m) * D + d] = v;
+      const double* yr = STAGE ? sy + (m - m0) * K : Y0p + (int64_t)m * K;
+      double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+      int kk = 0;
+      for (; kk + 4 <= K; kk += 4) {
+        v0 += yr[kk] * scf[kk * 17 + dd];
+        v1 += yr[kk + 1] * scf[(kk + 1) * 17 + dd];
+        v2 += yr[kk + 2] * scf[(kk + 2) * 17 + dd];
+        v3 += yr[kk + 3] * scf[(kk + 3) * 17 + dd];
+      }
+      for (; kk < K; ++kk) v0 += yr[kk] * scf[kk * 17 + dd];
+      Xb[((int64_t)f * M + m) * D + d] = (v0 + v1) + (v2 + v3);
     }
   }
 }

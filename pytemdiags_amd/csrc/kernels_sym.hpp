@@ -63,22 +63,26 @@ __device__ __forceinline__ constexpr int sym_harm(int tb, int i) {
 // ------------------------------------------------------------------------------------------------
 // paired project sweep (sweep 1): partial[split][f][l][d] over this split's pairs
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NF, int TBS>
-__global__ void __launch_bounds__(256, 2)
+// NFW fields per wave: the workgroup's 4 waves cover DPW = 4*NFW/NF d-tiles x NF/NFW field groups
+// (NFW = 1 for small ragged D, like the generic sweep's config E).
+template <typename T, int NF, int NFW, int TBS, int WPS>
+__global__ void __launch_bounds__(256, WPS)
 project_sym_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict__ ysym,
                    const int* __restrict__ rows, int64_t npg, int64_t npg4, const double* __restrict__ colscale,
                    int sfield, double* __restrict__ partial, int nsplit, int ndt) {
+  constexpr int DPW = 4 * NFW / NF;
   constexpr int NB = 2 * TBS;                 // blocks per pair-group
   constexpr int CH = SYM_PROJ_CH;             // pair-groups per chunk (CH*8 physical rows)
   constexpr int YE = CH * NB * 16;
   constexpr int YJ = (YE + 255) / 256;
   __shared__ double ystage[2][YE];
   int split, dq;
-  if (!wg_work((ndt + 3) >> 2, nsplit, split, dq)) return;
+  if (!wg_work((ndt + DPW - 1) / DPW, nsplit, split, dq)) return;
   const int wave = uniform_wave();
   const int tid = threadIdx.x, lane = tid & 63;
   const int c = lane & 15, g = lane >> 4;
-  const int dt = dq * 4 + wave;
+  const int dt = dq * DPW + wave % DPW;
+  const int f0 = (wave / DPW) * NFW;          // first field of this wave
   const bool active = dt < ndt;
   const int64_t d = (int64_t)dt * 16 + c;
   const bool dvalid = active && d < D;
@@ -87,20 +91,20 @@ project_sym_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
   const int c0 = (int)(nchunk * split / nsplit), c1 = (int)(nchunk * (split + 1) / nsplit);
   const uint32_t yoff = (uint32_t)(g * 4 + (lane & 3));
 
-  double sc[NF];
-  const T* fb[NF];
+  double sc[NFW];
+  const T* fb[NFW];
 #pragma unroll
-  for (int f = 0; f < NF; ++f) {
-    sc[f] = (colscale != nullptr && f == sfield) ? colscale[dcl] : 1.0;
-    fb[f] = reinterpret_cast<const T*>(fp.p[f]) + dcl;
+  for (int f = 0; f < NFW; ++f) {
+    sc[f] = (colscale != nullptr && f0 + f == sfield) ? colscale[dcl] : 1.0;
+    fb[f] = reinterpret_cast<const T*>(fp.p[f0 + f]) + dcl;
   }
-  double acc[NF][NB];
+  double acc[NFW][NB];
 #pragma unroll
-  for (int f = 0; f < NF; ++f)
+  for (int f = 0; f < NFW; ++f)
 #pragma unroll
     for (int t = 0; t < NB; ++t) acc[f][t] = 0.0;
 
-  T xn[NF][CH], xs[NF][CH];
+  T xn[NFW][CH], xs[NFW][CH];
   int rn[CH], rs[CH];       // row indices of the chunk after next (index loads run two chunks ahead)
   double ys[YJ];
   auto load_rows = [&](int chunk) __attribute__((always_inline)) {
@@ -114,7 +118,7 @@ project_sym_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
     const int64_t on = (int64_t)rn[ti] * D;
     const int64_t os = (int64_t)(rs[ti] < 0 ? rn[ti] : rs[ti]) * D;
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
+    for (int f = 0; f < NFW; ++f) {
       xn[f][ti] = fb[f][on];
       xs[f][ti] = fb[f][os];
     }
@@ -149,9 +153,9 @@ project_sym_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
     if (active) {
 #pragma unroll
       for (int ti = 0; ti < CH; ++ti) {
-        double ss[NF], dd[NF];
+        double ss[NFW], dd[NFW];
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
+        for (int f = 0; f < NFW; ++f) {
           const double a = (double)xn[f][ti] * sc[f];
           const double b = has_s[ti] ? (double)xs[f][ti] * sc[f] : 0.0;
           ss[f] = a + b;
@@ -165,7 +169,7 @@ project_sym_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
         for (int t = 0; t < NB; ++t) {
           const double ya = yst[(ti * NB + t) * 16 + yoff];
 #pragma unroll
-          for (int f = 0; f < NF; ++f) acc[f][t] = TEMX_MFMA4(ya, t < TBS ? ss[f] : dd[f], acc[f][t]);
+          for (int f = 0; f < NFW; ++f) acc[f][t] = TEMX_MFMA4(ya, t < TBS ? ss[f] : dd[f], acc[f][t]);
         }
       }
     }
@@ -174,11 +178,11 @@ project_sym_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
 
   if (dvalid) {
 #pragma unroll
-    for (int f = 0; f < NF; ++f)
+    for (int f = 0; f < NFW; ++f)
 #pragma unroll
       for (int t = 0; t < NB; ++t) {
         const int l = sym_harm<TBS>(t, g);
-        if (l < K) partial[(((int64_t)split * NF + f) * K + l) * D + d] = acc[f][t];
+        if (l < K) partial[(((int64_t)split * NF + f0 + f) * K + l) * D + d] = acc[f][t];
       }
   }
 }

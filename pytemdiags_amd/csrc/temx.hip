@@ -213,6 +213,7 @@ static int launch_project_c(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t D, c
   return TEMX_OK;
 }
 
+constexpr int SYM_PROJ_E_WPS = 3;
 struct ProjCfg3 { static constexpr int NFW = 3, PD = 1, WPS = 2; };   // the 3 eddy products (large-L path)
 
 template <typename T, int NF>
@@ -253,19 +254,33 @@ static int launch_reduce(temx_plan* pl, const double* partial, int nsplit, int64
 
 static int launch_solve(temx_plan* pl, const double* B, int NF, int64_t D, double* C, double* Xb,
                         hipStream_t st) {
-  // slices of the output latitudes so that small problems still give >= ~2 blocks per CU
-  const int64_t base = ((D + 15) / 16) * NF;
-  int ms = Xb ? (int)std::min<int64_t>(12, std::max<int64_t>(1, (2 * pl->num_cu + base - 1) / base)) : 1;
+  // 16 waves per block (the solve is latency bound: one round of dot products per phase); slices of
+  // 64 output latitudes = one zonal-mean output per thread
+  const int ms = Xb ? (pl->M + 63) / 64 : 1;
   dim3 grid((unsigned)((D + 15) / 16), NF, ms);
-  const size_t slds = (size_t)2 * pl->K4 * 17 * sizeof(double);
-  static bool solve_attr = false;
-  if (!solve_attr && slds > 48 * 1024) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    solve_attr = true;
+  const int mper = (pl->M + ms - 1) / ms;
+  if (pl->K <= 64) {
+    const size_t slds = ((size_t)2 * pl->K4 * 17 + (size_t)pl->K * pl->K + (Xb ? (size_t)mper * pl->K : 0)) * sizeof(double);
+    static bool attr = false;
+    if (!attr) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_kernel<true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr = true;
+    }
+    if (slds > 160 * 1024) return fail(TEMX_EUNSUPPORTED, "M = %d output latitudes: solve staging exceeds LDS", pl->M);
+    hipLaunchKernelGGL(solve_kernel<true>, grid, dim3(1024), slds, st, B, pl->K, pl->K4, pl->M, D, pl->Ginv.d(),
+                       pl->Y0p.d(), C, Xb);
+  } else {
+    const size_t slds = (size_t)2 * pl->K4 * 17 * sizeof(double);
+    static bool attr = false;
+    if (!attr) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_kernel<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr = true;
+    }
+    hipLaunchKernelGGL(solve_kernel<false>, grid, dim3(1024), slds, st, B, pl->K, pl->K4, pl->M, D, pl->Ginv.d(),
+                       pl->Y0p.d(), C, Xb);
   }
-  hipLaunchKernelGGL(solve_kernel, grid, dim3(256), slds, st, B, pl->K, pl->K4, pl->M, D, pl->Ginv.d(),
-                     pl->Y0p.d(), C, Xb);
   HIPCHK(hipGetLastError());
   return TEMX_OK;
 }
@@ -404,15 +419,24 @@ template <typename T, int NF>
 static int launch_project_sym_t(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t D, const double* colscale,
                                 int sfield, double* partial, const Split& sp, hipStream_t st) {
   dim3 grid(sp.grid), block(256);
-#define TEMX_LPS(TBSv)                                                                              \
-  hipLaunchKernelGGL((project_sym_kernel<T, NF, TBSv>), grid, block, 0, st, fp, D, pl->K,           \
+#define TEMX_LPS(TBSv, NFWv, WPSv)                                                                  \
+  hipLaunchKernelGGL((project_sym_kernel<T, NF, NFWv, TBSv, WPSv>), grid, block, 0, st, fp, D, pl->K, \
                      pl->ysym.d(), static_cast<const int*>(pl->rows.p), pl->npg, pl->npg_alloc * 4, \
                      colscale, sfield, partial, sp.nsplit, sp.ndt)
-  switch (pl->TBS) {
-    case 2: TEMX_LPS(2); break;
-    case 4: TEMX_LPS(4); break;
-    case 7: TEMX_LPS(7); break;
-    default: TEMX_LPS(8); break;
+  if (NF == 4 && sp.dpw == 1) {     // small ragged D: one d-tile per workgroup, one field per wave
+    switch (pl->TBS) {
+      case 2: TEMX_LPS(2, 1, SYM_PROJ_E_WPS); break;
+      case 4: TEMX_LPS(4, 1, SYM_PROJ_E_WPS); break;
+      case 7: TEMX_LPS(7, 1, SYM_PROJ_E_WPS); break;
+      default: TEMX_LPS(8, 1, SYM_PROJ_E_WPS); break;
+    }
+  } else {
+    switch (pl->TBS) {
+      case 2: TEMX_LPS(2, NF, 2); break;
+      case 4: TEMX_LPS(4, NF, 2); break;
+      case 7: TEMX_LPS(7, NF, 2); break;
+      default: TEMX_LPS(8, NF, 2); break;
+    }
   }
 #undef TEMX_LPS
   HIPCHK(hipGetLastError());
@@ -973,9 +997,11 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
     const int64_t nch = (pl->npg + SYM_PROJ_CH - 1) / SYM_PROJ_CH;
     pl->sp_sproj4 = Split();
     pl->sp_sproj1 = Split();
-    if (pick_dpw(ndt_, 4) == 4) {     // the paired project sweep is built for quads of d-tiles
+    if (pick_dpw(ndt_, 4) == 4) {     // quads of d-tiles, all four fields per wave
       pl->sp_sproj4 = choose_split(D, nch, 2 * pl->num_cu, 4);
       pl->sp_sproj1 = choose_split(D, nch, 2 * pl->num_cu, 4);
+    } else {                          // small ragged D: one d-tile per workgroup, one field per wave
+      pl->sp_sproj4 = choose_split(D, nch, SYM_PROJ_E_WPS * pl->num_cu, 1);
     }
     pl->sp_seddy = choose_split(D, pl->npg / (8 / edpw), pl->num_cu, edpw);
     const size_t need2 = (size_t)std::max({pl->sp_sproj4.nsplit * 4, pl->sp_seddy.nsplit * (8 / edpw) * 3,
