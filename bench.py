@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--cpu-sample-nt", type=int, default=2)
     ap.add_argument("--no-symmetry", action="store_true",
                     help="force the generic sweeps (do not use mirror pairing of the symmetric grid)")
+    ap.add_argument("--no-ncol-extra", action="store_true",
+                    help="N > 1, time sharding: skip the extra strong-scaling run of the same job ncol-sharded "
+                         "over RCCL (reported as \"ncol_sharded\", not the metric)")
     ap.add_argument("--also", default="ne30x72x1",
                     help="comma list of extra (small) workloads timed after the main one, N=1 only")
     args = ap.parse_args()
@@ -101,11 +104,18 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
+    # TEMX_BENCH_BACKEND=gloo rehearses the N > 1 control flow with several ranks on one GPU
+    backend = os.environ.get("TEMX_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     from pytemdiags_amd import engine, sharding, synth
 
@@ -250,6 +260,54 @@ def main():
         rec["parity_vs_oracle_on_sample"] = {"max_field_normalised_err": err, "tolerance": 1e-10,
                                             "ok": bool(err <= 1e-10 and not bad)}
     plan.close()
+
+    if world > 1 and not use_ncol and not args.no_ncol_extra:
+        # BASELINE config 4: the same job (one ne120x72x30 block in total) with the columns sharded over
+        # the ranks and the zonal sums all-reduced over RCCL/xGMI -- strong scaling, reported beside
+        # the metric.  A watchdog prints the main record and leaves if a collective stalls.
+        import signal
+
+        def _stalled(signum, frame):
+            rec["ncol_sharded"] = {"error": "timed out"}
+            if rank == 0:
+                print(json.dumps(rec), flush=True)
+            os._exit(0)
+
+        signal.signal(signal.SIGALRM, _stalled)
+        signal.alarm(240)
+        try:
+            del fields, out
+            torch.cuda.empty_cache()
+            mine = sharding.symmetric_ncol_shards(lat, world)[rank]
+            p3 = engine.Plan(lat[mine], lat_zm, K_HARM - 1, device=local_rank, defer_finalize=True,
+                             symmetry=not args.no_symmetry)
+            runner3 = sharding.NcolShardedTEM(p3)           # all-reduce of the Gram matrix
+            p3.set_tem(nlev, nt, plev * 100)
+            f3 = engine.synth_fields(local_rank, lat[mine], lon[mine], plev, nt, t0=0, dtype=tdtype, seed=0)
+            for _ in range(max(args.warmup, 1)):
+                runner3.run(*f3)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                runner3.run(*f3)
+            barrier()
+            e3 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(e3, op=dist.ReduceOp.MAX)
+            e3 = float(e3.item())
+            bad3 = p3.status()
+            rec["ncol_sharded"] = {
+                "scaling": "strong", "value": ncol * nlev * nt * args.steps / e3, "unit": "grid-points/s",
+                "ms_per_step": e3 / args.steps * 1e3, "n_gpus": world,
+                "workload": "ne%d (%d cols) x %d lev x %d snapshots per job, columns sharded in whole mirror pairs"
+                            % (ne, ncol, nlev, nt),
+                "collectives": "2 RCCL all-reduces per step ([4][K][D] and [3][K][D] fp64 = %d bytes) + the "
+                               "K x K Gram matrix once at plan build" % (7 * K_HARM * nlev * nt * 8),
+                "mirror_paired_sweeps": bool(p3.paired), "nonfinite": bool(bad3)}
+            p3.close()
+        except Exception as e:  # noqa: BLE001 - the metric line must survive a failure of the extra
+            rec["ncol_sharded"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        signal.alarm(0)
+
     if rank == 0:
         print(json.dumps(rec), flush=True)
     if world > 1:

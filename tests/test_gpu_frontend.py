@@ -182,3 +182,34 @@ def test_tracer_staged_equals_fused():
     t2, _ = plan.tracer_stage3(Bq2)
     assert torch.equal(t1, t2) and not plan.status()
     plan.close()
+
+
+def test_latlon_grid_zonal_mean_is_the_longitude_average():
+    """Structured data through format_latlon_data (tem_util.py:247-342).  On a regular lat-lon grid
+    Y0^T A only sees the longitude sums, so for a profile inside span{Y_l^0, l <= L} (a polynomial
+    of degree <= L in sin(lat)) plus any zonally varying part that averages out, the
+    spherical-harmonic zonal mean IS the profile -- no CPU reference needed, any size."""
+    from pytemdiags_amd import sph_zonal_averager, LabeledArray
+    from pytemdiags_amd.tem_util import format_latlon_data
+    nlat, nlon, nlev = 181, 360, 7
+    lat = np.linspace(-90, 90, nlat)
+    lon = np.arange(nlon) * (360.0 / nlon)
+    s = np.sin(np.deg2rad(lat))
+    prof = lambda x, k: 1.0 + 0.5 * x - 2.0 * x ** 2 + 0.3 * x ** (5 + k)       # noqa: E731
+    lam = np.deg2rad(lon)
+    f = np.empty((nlat, nlon, nlev))
+    for k in range(nlev):
+        f[:, :, k] = prof(s, k)[:, None] + (3.0 + k) * np.cos((k + 1) * lam)[None, :] * np.cos(np.deg2rad(lat))[:, None] ** 2
+    data = format_latlon_data({"lat": LabeledArray(lat, ("lat",)), "lon": LabeledArray(lon, ("lon",)),
+                               "F": LabeledArray(f, ("lat", "lon", "lev"), name="F")})
+    lat_out = np.linspace(-88, 88, 45)
+    ZM = sph_zonal_averager(data["lat"].values, lat_out, 20)
+    ZM.sph_compute_matrices()
+    zm = ZM.sph_zonal_mean(data["F"])
+    assert zm.dims == ("lat", "lev")
+    so = np.sin(np.deg2rad(lat_out))
+    for k in range(nlev):
+        assert np.max(np.abs(zm.values[:, k] - prof(so, k))) < 1e-11, k
+    zmn = ZM.sph_zonal_mean_native(data["F"]).values.reshape(nlat, nlon, nlev)
+    for k in range(nlev):
+        assert np.max(np.abs(zmn[:, :, k] - prof(s, k)[:, None])) < 1e-11, k
