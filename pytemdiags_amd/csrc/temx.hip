@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "kernels.hpp"
@@ -149,6 +150,17 @@ static Split choose_split(int64_t D, int64_t nchunk, int slots, int dpw = 4) {
   return s;
 }
 
+
+// hipFuncSetAttribute is per device: remember, per kernel instantiation, which devices have the
+// dynamic-LDS limit raised (a process may own plans on several GPUs).
+static int lds_attr_once(std::atomic<uint64_t>& done, int device, const void* fn, int bytes) {
+  const uint64_t bit = 1ull << (device & 63);
+  if (done.load(std::memory_order_acquire) & bit) return TEMX_OK;
+  HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.fetch_or(bit, std::memory_order_release);
+  return TEMX_OK;
+}
+
 static void time_begin(temx_plan* pl, int which, hipStream_t st, TimedLaunch& tl) {
   (void)which;
   if (!pl->timing) return;
@@ -261,23 +273,15 @@ static int launch_solve(temx_plan* pl, const double* B, int NF, int64_t D, doubl
   const int mper = (pl->M + ms - 1) / ms;
   if (pl->K <= 64) {
     const size_t slds = ((size_t)2 * pl->K4 * 17 + (size_t)pl->K * pl->K + (Xb ? (size_t)mper * pl->K : 0)) * sizeof(double);
-    static bool attr = false;
-    if (!attr) {
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_kernel<true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr = true;
-    }
+    static std::atomic<uint64_t> attr{0};
+    if (int rc = lds_attr_once(attr, pl->device, reinterpret_cast<const void*>(solve_kernel<true>), 160 * 1024)) return rc;
     if (slds > 160 * 1024) return fail(TEMX_EUNSUPPORTED, "M = %d output latitudes: solve staging exceeds LDS", pl->M);
     hipLaunchKernelGGL(solve_kernel<true>, grid, dim3(1024), slds, st, B, pl->K, pl->K4, pl->M, D, pl->Ginv.d(),
                        pl->Y0p.d(), C, Xb);
   } else {
     const size_t slds = (size_t)2 * pl->K4 * 17 * sizeof(double);
-    static bool attr = false;
-    if (!attr) {
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_kernel<false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr = true;
-    }
+    static std::atomic<uint64_t> attr{0};
+    if (int rc = lds_attr_once(attr, pl->device, reinterpret_cast<const void*>(solve_kernel<false>), 160 * 1024)) return rc;
     hipLaunchKernelGGL(solve_kernel<false>, grid, dim3(1024), slds, st, B, pl->K, pl->K4, pl->M, D, pl->Ginv.d(),
                        pl->Y0p.d(), C, Xb);
   }
@@ -294,12 +298,9 @@ static int launch_eddy_d(temx_plan* pl, const FieldPtrs<4>& fp, const double* C,
   do {                                                                                                \
     auto kern = eddy_kernel<T, TBv, MODE, DPW, KIND>;                                                 \
     const size_t lds = ((size_t)DPW * NFR * TBv * 64 + 8 * EDDY_GR * TBv * 16) * sizeof(double);      \
-    static bool attr_set = false;   /* once per instantiation (per process) */                        \
-    if (!attr_set) {                                                                                  \
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                 \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
-      attr_set = true;                                                                                \
-    }                                                                                                 \
+    static std::atomic<uint64_t> attr_set{0};   /* per instantiation, one bit per device */           \
+    if (int rc_ = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(kern), (int)lds)) \
+      return rc_;                                                                                     \
     hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->N, pl->D, pl->K, pl->yblk.d(),             \
                        pl->nchunk, pl->colscale.d(), C, partial, sp.nsplit, sp.ndt, eo);              \
   } while (0)
@@ -461,12 +462,9 @@ static int launch_eddy_sym_d(temx_plan* pl, const FieldPtrs<4>& fp, const double
   do {                                                                                                \
     auto kern = eddy_sym_kernel<T, TBSv, MODE, DPW, KIND>;                                            \
     const size_t lds = ((size_t)DPW * NFR * 2 * TBSv * 64 + 8 * 2 * TBSv * 16) * sizeof(double);      \
-    static bool attr_set = false;   /* once per instantiation (per process) */                        \
-    if (!attr_set) {                                                                                  \
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                 \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
-      attr_set = true;                                                                                \
-    }                                                                                                 \
+    static std::atomic<uint64_t> attr_set{0};   /* per instantiation, one bit per device */           \
+    if (int rc_ = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(kern), (int)lds)) \
+      return rc_;                                                                                     \
     hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->D, pl->K, pl->K4, pl->ysym.d(),            \
                        static_cast<const int*>(pl->rows.p), pl->npg, pl->npg_alloc * 4, pl->npair,    \
                        pl->colscale.d(), C, partial, sp.nsplit, sp.ndt, eo);                          \
