@@ -46,7 +46,8 @@ enum {
 
 enum {
   TEMX_DEFER_FINALIZE = 1,
-  TEMX_NO_SYMMETRY = 2   /* do not use the mirror-paired sweeps even if the grid is equatorially symmetric */
+  TEMX_NO_SYMMETRY = 2,  /* generic sweeps only: neither latitude classes nor mirror pairing */
+  TEMX_NO_CLASSES = 4    /* do not use the latitude-class sweeps (mirror pairing is still tried) */
 };
 
 /* which matrix temx_get_matrix copies */
@@ -109,6 +110,9 @@ void temx_plan_destroy(temx_plan* plan);
 
 /* 1 if the plan runs the mirror-paired sweeps (equatorially symmetric grid detected), else 0. */
 int temx_plan_is_paired(const temx_plan* plan);
+/* 0 generic sweeps, 1 mirror-paired sweeps, 2 latitude-class sweeps (columns that share |lat| share a
+ * basis row: cubed-sphere, lat-lon and Gaussian grids; TEMX_NO_CLS=1 in the environment disables) */
+int temx_plan_sweep_mode(const temx_plan* plan);
 
 int temx_get_matrix(temx_plan* plan, int which, double* dst, void* stream);
 

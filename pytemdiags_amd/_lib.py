@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libtemx.so")
 F64, F32 = 0, 1
 DEFER_FINALIZE = 1
 NO_SYMMETRY = 2
+NO_CLASSES = 4
 MAT_Y0, MAT_Y0P, MAT_GRAM, MAT_GINV, MAT_Y0INV = 0, 1, 2, 3, 4
 
 RESULT_NAMES = ("vtem", "omegatem", "wtem", "psitem", "epfy", "epfz", "epdiv",
@@ -40,6 +41,7 @@ SIGNATURES = [
     ("temx_plan_set_weights", _i, [_vp, _dp]),
     ("temx_plan_destroy", None, [_vp]),
     ("temx_plan_is_paired", _i, [_vp]),
+    ("temx_plan_sweep_mode", _i, [_vp]),
     ("temx_get_matrix", _i, [_vp, _i, _vp, _vp]),
     ("temx_project", _i, [_vp, _vp, _i, _i64, _vp, _vp]),
     ("temx_zonal_mean", _i, [_vp, _vp, _i, _i64, _vp, _i, _vp]),

@@ -1,0 +1,413 @@
+// kernels_cls.hpp -- latitude-class sweeps: native columns that share a latitude share a basis row.
+//
+// Y_l^0 depends on latitude only.  On the grids this code meets (cubed-sphere: 8 columns per
+// latitude and hemisphere by the symmetry of the cube; lat-lon / Gaussian: NLON columns per
+// latitude) many native columns have the same |lat|.  For a class c of such columns, with northern
+// members N(c) and southern members S(c) (Y_l^0(-lat) = (-1)^l Y_l^0(lat)):
+//   projection      sum_i Y0[i][l] x_i  =  sum_c Y_l(lat_c) ( sum_{N(c)} x  +-  sum_{S(c)} x )
+//   reconstruction  xbar is the same for every member of a side:  xbar_N = E + O,  xbar_S = E - O
+// so the MFMA work is per CLASS, not per column: 1/8 of the generic sweeps on a cubed sphere, and
+// the sweeps turn from MFMA bound into pure HBM streams (one v_add / a few VALU ops per element).
+// The mirror-paired sweeps of kernels_sym.hpp are the special case of one member per side.
+//
+// Tables (built on the host, temx.hip build_classes):
+//   classes are sorted by (members N, members S) so that the 4 classes of a class-group (the MFMA
+//   k dimension) have equal counts; a group is walked in batches of CLS_MB member rows per class,
+//   first its northern batches, then its southern ones.
+//   crow[batch][g][j]  int32: member row j of class g of the batch's group (one int4 per 16-lane
+//                      group), | side << 28 | first-batch-of-group << 29 | last << 30; bit 31 =
+//                      padding (no member: row 0 is read and weighted 0).  Every entry of a batch
+//                      carries the batch flags.  Padded by two batches.
+//   ycls[group][2*TBS][16]  4x4 blocks at the class latitudes, layout of kernels_sym.hpp's ysym.
+//   csplit[nsub+1]     (first batch, first group) of every piece of work; cuts at group boundaries.
+// No workgroup barriers: each wave stages its own Y blocks (wave-private LDS) and walks its own
+// flat batch list with the X loads one batch ahead and the row indices two.
+#pragma once
+#include "kernels_sym.hpp"
+
+namespace temx {
+
+constexpr int CLS_MB = 4;                     // member rows per class and batch
+constexpr int CLS_ROWMASK = 0x0FFFFFFF;
+constexpr int CLS_SOUTH = 1, CLS_FIRST = 2, CLS_LAST = 4;   // flags, stored at bit 28
+
+__global__ void cls_basis_kernel(const double* __restrict__ xc, int64_t ncls, int64_t ncls_pad, int K, int TBS,
+                                 const double* __restrict__ norm, double* __restrict__ ycls) {
+  int64_t ci = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (ci >= ncls_pad) return;
+  const bool valid = ci < ncls;
+  const double xv = valid ? xc[ci] : 0.0;
+  const int64_t grp = ci >> 2;
+  const int k = (int)(ci & 3);
+  double* blk = ycls + grp * (2 * TBS * 16);
+  double pm1 = 1.0, pc = xv;
+  for (int l = 0; l < 8 * TBS; ++l) {
+    double P;
+    if (l == 0) {
+      P = 1.0;
+    } else if (l == 1) {
+      P = xv;
+    } else {
+      double pn = ((2 * l - 1) * xv * pc - (l - 1) * pm1) / l;
+      pm1 = pc;
+      pc = pn;
+      P = pn;
+    }
+    const double val = (valid && l < K) ? norm[l] * P : 0.0;
+    const int h = l >> 1;
+    const int t = (l & 1) * TBS + (h >> 2);
+    blk[t * 16 + k * 4 + (h & 3)] = val;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// class project sweep (sweep 1)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NF, int NFW, int TBS, int WPS>
+__global__ void __launch_bounds__(256, WPS)
+project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict__ ycls,
+                   const int4* __restrict__ crow, const int2* __restrict__ csplit,
+                   const double* __restrict__ colscale, int sfield, double* __restrict__ partial, int nsplit,
+                   int ndt) {
+  constexpr int DPW = 4 * NFW / NF;
+  constexpr int NB = 2 * TBS;
+  constexpr int YE = NB * 16;
+  constexpr int YJ = (YE + 63) / 64;
+  constexpr int MB = CLS_MB;
+  __shared__ double ystage[4][YE];            // wave private
+  int split, dq;
+  if (!wg_work((ndt + DPW - 1) / DPW, nsplit, split, dq)) return;
+  const int wave = uniform_wave(), lane = threadIdx.x & 63;
+  const int c = lane & 15, g = lane >> 4;
+  const int dt = dq * DPW + wave % DPW;
+  const int f0 = (wave / DPW) * NFW;
+  if (dt >= ndt) return;                      // (no barriers below)
+  const int64_t d = (int64_t)dt * 16 + c;
+  const bool dvalid = d < D;
+  const int64_t dcl = dvalid ? d : D - 1;
+  const int b0 = __builtin_amdgcn_readfirstlane(csplit[split].x);
+  const int b1 = __builtin_amdgcn_readfirstlane(csplit[split + 1].x);
+  int grp = __builtin_amdgcn_readfirstlane(csplit[split].y);
+  const uint32_t yoff = (uint32_t)(g * 4 + (lane & 3));
+  double* yst = ystage[wave];
+
+  double sc[NFW];
+  const T* fb[NFW];
+#pragma unroll
+  for (int f = 0; f < NFW; ++f) {
+    sc[f] = (colscale != nullptr && f0 + f == sfield) ? colscale[dcl] : 1.0;
+    fb[f] = reinterpret_cast<const T*>(fp.p[f0 + f]) + dcl;
+  }
+  double acc[NFW][NB];
+#pragma unroll
+  for (int f = 0; f < NFW; ++f)
+#pragma unroll
+    for (int t = 0; t < NB; ++t) acc[f][t] = 0.0;
+  double sN[NFW], sS[NFW];
+#pragma unroll
+  for (int f = 0; f < NFW; ++f) sN[f] = sS[f] = 0.0;
+
+  T xb[2][MB][NFW];
+  int er[2][MB];
+  int fl[2] = {0, 0};
+  double ys[YJ];
+  auto load_ys = [&](int gi) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < YJ; ++j) ys[j] = (ycls + (int64_t)gi * YE)[(lane + 64 * j) < YE ? (lane + 64 * j) : 0];
+  };
+  auto issue = [&](auto pc, const int4 rv) __attribute__((always_inline)) {
+    constexpr int P = decltype(pc)::value;
+    er[P][0] = rv.x; er[P][1] = rv.y; er[P][2] = rv.z; er[P][3] = rv.w;
+    fl[P] = __builtin_amdgcn_readfirstlane(rv.x) >> 28;
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+      const int64_t off = (int64_t)(er[P][j] & CLS_ROWMASK) * D;
+#pragma unroll
+      for (int f = 0; f < NFW; ++f) xb[P][j][f] = fb[f][off];
+    }
+  };
+  int4 rn;
+  auto step = [&](auto pc, int b) __attribute__((always_inline)) {
+    constexpr int P = decltype(pc)::value;
+    if (b + 1 < b1) {                         // index load first: it must not queue behind the X loads
+      const int4 r1 = rn;
+      rn = crow[(int64_t)(b + 2) * 4 + g];
+      issue(std::integral_constant<int, P ^ 1>{}, r1);
+    }
+    const int flags = fl[P];
+    double wt[MB];                            // padding entries read row 0 and weigh nothing
+#pragma unroll
+    for (int j = 0; j < MB; ++j) wt[j] = er[P][j] < 0 ? 0.0 : 1.0;
+    if (flags & CLS_SOUTH) {
+#pragma unroll
+      for (int j = 0; j < MB; ++j)
+#pragma unroll
+        for (int f = 0; f < NFW; ++f) sS[f] += wt[j] * (double)xb[P][j][f];
+    } else {
+#pragma unroll
+      for (int j = 0; j < MB; ++j)
+#pragma unroll
+        for (int f = 0; f < NFW; ++f) sN[f] += wt[j] * (double)xb[P][j][f];
+    }
+    if (flags & CLS_LAST) {
+#pragma unroll
+      for (int j = 0; j < YJ; ++j)
+        if (lane + 64 * j < YE) yst[lane + 64 * j] = ys[j];
+      ++grp;
+      load_ys(grp);                           // ycls is padded by one group
+      double ss[NFW], dd[NFW];
+#pragma unroll
+      for (int f = 0; f < NFW; ++f) {
+        ss[f] = (sN[f] + sS[f]) * sc[f];
+        dd[f] = (sN[f] - sS[f]) * sc[f];
+        sN[f] = sS[f] = 0.0;
+      }
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        const double ya = yst[t * 16 + yoff];
+#pragma unroll
+        for (int f = 0; f < NFW; ++f) acc[f][t] = TEMX_MFMA4(ya, t < TBS ? ss[f] : dd[f], acc[f][t]);
+      }
+    }
+  };
+
+  if (b0 < b1) {
+    load_ys(grp);
+    rn = crow[(int64_t)b0 * 4 + g];
+    const int4 r0 = rn;
+    rn = crow[(int64_t)(b0 + 1) * 4 + g];      // padded: in bounds
+    issue(std::integral_constant<int, 0>{}, r0);
+    for (int b = b0; b < b1; b += 2) {
+      step(std::integral_constant<int, 0>{}, b);
+      if (b + 1 < b1) step(std::integral_constant<int, 1>{}, b + 1);
+    }
+  }
+
+  // (an empty range still stores its zero slab: the reduction sums every slab)
+  if (dvalid) {
+#pragma unroll
+    for (int f = 0; f < NFW; ++f)
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        const int l = sym_harm<TBS>(t, g);
+        if (l < K) partial[(((int64_t)split * NF + f0 + f) * K + l) * D + d] = acc[f][t];
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// class eddy / flux sweep (sweep 2).  Per class-group: 4 reconstructions (once), the eddies and
+// products of every member row against its side's zonal mean (VALU), 3 projections of the
+// per-class product sums (once).  Template parameters as eddy_sym_kernel.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int TBS, int MODE, int DPW, int KIND>
+__global__ void __launch_bounds__(512, 2)
+eddy_cls_kernel(FieldPtrs<4> fp, int64_t D, int K, int K4, const double* __restrict__ ycls,
+                const int4* __restrict__ crow, const int2* __restrict__ csplit,
+                const double* __restrict__ colscale, const double* __restrict__ C,
+                double* __restrict__ partial, int nsplit, int ndt, EddyOut eo) {
+  extern __shared__ double lds[];
+  constexpr int NB = 2 * TBS;
+  constexpr int YE = NB * 16;
+  constexpr int YJ = (YE + 63) / 64;
+  constexpr int NP = 8 / DPW;
+  constexpr int NFR = KIND == 0 ? 4 : 3;
+  constexpr int NPR = KIND == 0 ? 3 : 2;
+  constexpr int MB = CLS_MB;
+  int split, dq;
+  if (!wg_work((ndt + DPW - 1) / DPW, nsplit, split, dq)) return;
+  const int wave = uniform_wave(), lane = threadIdx.x & 63;
+  const int w4 = wave % DPW, part = wave / DPW;
+  const int c = lane & 15, g = lane >> 4;
+  const int dt = dq * DPW + w4;
+  if (dt >= ndt) return;
+  const int64_t d = (int64_t)dt * 16 + c;
+  const bool dvalid = d < D;
+  const int64_t dcl = dvalid ? d : D - 1;
+  const int64_t sub = (int64_t)split * NP + part;
+  const int b0 = __builtin_amdgcn_readfirstlane(csplit[sub].x);
+  const int b1 = __builtin_amdgcn_readfirstlane(csplit[sub + 1].x);
+  int grp = __builtin_amdgcn_readfirstlane(csplit[sub].y);
+
+  // coefficient B operands, even blocks then odd blocks: cb[f][tb][lane] = C_f[harm(tb, g)][d]
+  {
+    double* cb = lds + (size_t)w4 * (NFR * NB * 64) + lane;
+#pragma unroll
+    for (int f = 0; f < NFR; ++f) {
+      double v[NB];
+#pragma unroll
+      for (int tb = 0; tb < NB; ++tb) {
+        const int l = sym_harm<TBS>(tb, g);
+        const int lc = l < K ? l : K - 1;
+        v[tb] = C[((int64_t)f * K4 + lc) * D + dcl];
+      }
+#pragma unroll
+      for (int tb = 0; tb < NB; ++tb) cb[(f * NB + tb) * 64] = sym_harm<TBS>(tb, g) < K ? v[tb] : 0.0;
+    }
+  }
+  int cbi = w4 * (NFR * NB * 64) + lane;
+  double* yst = lds + DPW * NFR * NB * 64 + wave * YE;
+  // the slab is shared by the NP waves of a d-tile; each wave wrote all of it (same values), so a
+  // wave only depends on its own stores -- no barrier
+
+  const double sth = (KIND == 0 && colscale != nullptr) ? colscale[dcl] : 1.0;
+  const uint32_t aoff_r = (uint32_t)((lane & 3) * 4 + g);
+  const uint32_t aoff_p = (uint32_t)(g * 4 + (lane & 3));
+  const T* fb[NFR];
+#pragma unroll
+  for (int f = 0; f < NFR; ++f) fb[f] = reinterpret_cast<const T*>(fp.p[f]) + dcl;
+
+  double acc[NPR][NB];
+#pragma unroll
+  for (int q = 0; q < NPR; ++q)
+#pragma unroll
+    for (int t = 0; t < NB; ++t) acc[q][t] = 0.0;
+  double xbN[NFR], xbS[NFR], pN[NPR], pS[NPR];
+#pragma unroll
+  for (int f = 0; f < NFR; ++f) xbN[f] = xbS[f] = 0.0;
+#pragma unroll
+  for (int q = 0; q < NPR; ++q) pN[q] = pS[q] = 0.0;
+
+  T xb[2][MB][NFR];
+  int er[2][MB];
+  int fl[2] = {0, 0};
+  double ys[YJ];
+  auto load_ys = [&](int gi) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < YJ; ++j) ys[j] = (ycls + (int64_t)gi * YE)[(lane + 64 * j) < YE ? (lane + 64 * j) : 0];
+  };
+  auto issue = [&](auto pc, const int4 rv) __attribute__((always_inline)) {
+    constexpr int P = decltype(pc)::value;
+    er[P][0] = rv.x; er[P][1] = rv.y; er[P][2] = rv.z; er[P][3] = rv.w;
+    fl[P] = __builtin_amdgcn_readfirstlane(rv.x) >> 28;
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+      const int64_t off = (int64_t)(er[P][j] & CLS_ROWMASK) * D;
+#pragma unroll
+      for (int f = 0; f < NFR; ++f) xb[P][j][f] = fb[f][off];
+    }
+  };
+  int4 rn;
+  auto step = [&](auto pc, int b) __attribute__((always_inline)) {
+    constexpr int P = decltype(pc)::value;
+    if (b + 1 < b1) {
+      const int4 r1 = rn;
+      rn = crow[(int64_t)(b + 2) * 4 + g];
+      issue(std::integral_constant<int, P ^ 1>{}, r1);
+    }
+    const int flags = fl[P];
+    if (flags & CLS_FIRST) {
+      // ---- reconstruction at the class latitudes: E = even-harmonic part, O = odd-harmonic part ----
+#pragma unroll
+      for (int j = 0; j < YJ; ++j)
+        if (lane + 64 * j < YE) yst[lane + 64 * j] = ys[j];
+      load_ys(grp + 1);                        // ycls is padded by one group
+      asm volatile("" : "+v"(cbi));            // keep the loop-invariant slab reads inside the loop
+      const double* cbr = lds + cbi;
+      double E[NFR], O[NFR];
+#pragma unroll
+      for (int f = 0; f < NFR; ++f) E[f] = O[f] = 0.0;
+#pragma unroll
+      for (int tb = 0; tb < NB; ++tb) {
+        const double ya = yst[tb * 16 + aoff_r];
+#pragma unroll
+        for (int f = 0; f < NFR; ++f) {
+          if (tb < TBS)
+            E[f] = TEMX_MFMA4(ya, cbr[(f * NB + tb) * 64], E[f]);
+          else
+            O[f] = TEMX_MFMA4(ya, cbr[(f * NB + tb) * 64], O[f]);
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < NFR; ++f) {
+        xbN[f] = E[f] + O[f];
+        xbS[f] = E[f] - O[f];
+      }
+    }
+    // ---- eddies and products of this batch's member rows ----
+    const bool south = (flags & CLS_SOUTH) != 0;
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+      const int ent = er[P][j];
+      const double w = ent < 0 ? 0.0 : 1.0;
+      double e[NFR], p[NPR];
+#pragma unroll
+      for (int f = 0; f < NFR; ++f) {
+        double x = (double)xb[P][j][f];
+        if (KIND == 0 && f == 2) x *= sth;
+        e[f] = x - (south ? xbS[f] : xbN[f]);
+      }
+      if (KIND == 0) {
+        p[0] = e[0] * e[1];
+        p[1] = e[0] * e[NFR - 1];
+        p[NPR - 1] = e[1] * e[2];
+      } else {
+        p[0] = e[0] * e[1];
+        p[1] = e[0] * e[2];
+      }
+      if (south) {
+#pragma unroll
+        for (int q = 0; q < NPR; ++q) pS[q] += w * p[q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < NPR; ++q) pN[q] += w * p[q];
+      }
+      if (MODE == 1) {
+        if (dvalid && ent >= 0) {
+          const int64_t o = (int64_t)(ent & CLS_ROWMASK) * D + d;
+          if (KIND == 0) {
+#pragma unroll
+            for (int f = 0; f < NFR; ++f)
+              if (eo.p[f]) eo.p[f][o] = e[f];
+          } else if (eo.p[0]) {
+            eo.p[0][o] = e[0];
+          }
+#pragma unroll
+          for (int q = 0; q < NPR; ++q)
+            if (eo.p[4 + q]) eo.p[4 + q][o] = p[q];
+        }
+      }
+    }
+    if (flags & CLS_LAST) {
+      // ---- projection: even harmonics see the class sums, odd harmonics the N - S differences ----
+      double sp[NPR], dp[NPR];
+#pragma unroll
+      for (int q = 0; q < NPR; ++q) {
+        sp[q] = pN[q] + pS[q];
+        dp[q] = pN[q] - pS[q];
+        pN[q] = pS[q] = 0.0;
+      }
+#pragma unroll
+      for (int tb = 0; tb < NB; ++tb) {
+        const double ya = yst[tb * 16 + aoff_p];
+#pragma unroll
+        for (int q = 0; q < NPR; ++q) acc[q][tb] = TEMX_MFMA4(ya, tb < TBS ? sp[q] : dp[q], acc[q][tb]);
+      }
+      ++grp;
+    }
+  };
+
+  if (b0 < b1) {
+    load_ys(grp);
+    rn = crow[(int64_t)b0 * 4 + g];
+    const int4 r0 = rn;
+    rn = crow[(int64_t)(b0 + 1) * 4 + g];
+    issue(std::integral_constant<int, 0>{}, r0);
+    for (int b = b0; b < b1; b += 2) {
+      step(std::integral_constant<int, 0>{}, b);
+      if (b + 1 < b1) step(std::integral_constant<int, 1>{}, b + 1);
+    }
+  }
+
+  if (dvalid && partial != nullptr) {
+#pragma unroll
+    for (int q = 0; q < NPR; ++q)
+#pragma unroll
+      for (int tb = 0; tb < NB; ++tb) {
+        const int l = sym_harm<TBS>(tb, g);
+        if (l < K) partial[((sub * NPR + q) * K + l) * D + d] = acc[q][tb];
+      }
+  }
+}
+
+}  // namespace temx

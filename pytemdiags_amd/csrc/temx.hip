@@ -10,12 +10,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <atomic>
 #include <vector>
 
 #include "kernels.hpp"
 #include "kernels_sym.hpp"
+#include "kernels_cls.hpp"
 
 using namespace temx;
 
@@ -106,6 +108,13 @@ struct temx_plan {
   DevBuf rows, ysym;
   Split sp_sproj4, sp_sproj1, sp_seddy;
   Split sp_proj4, sp_eddy;
+  // latitude-class path (columns sharing a latitude share a basis row), see kernels_cls.hpp
+  bool cls = false;
+  int64_t cgroups = 0, cbatches = 0, ncls = 0;
+  std::vector<int> gbatch0;            // first batch of every class-group (+ total)
+  DevBuf crow, ycls;
+  std::map<int, DevBuf> csplits;       // work cuts per number of pieces
+  Split sp_cproj4, sp_cproj1, sp_ceddy;
   // shared workspaces
   DevBuf partial;
   // operator-API workspace (any D)
@@ -375,6 +384,8 @@ static int project_all(temx_plan* pl, const FieldPtrs<NF>& fp, int dtype, int64_
 // ------------------------------------------------------------------------------------------------
 // mirror pairing of an equatorially symmetric grid (kernels_sym.hpp)
 // ------------------------------------------------------------------------------------------------
+static double sym_tol_deg();
+
 // Every column with lat > tol must have a partner with the opposite latitude (any longitude);
 // |lat| <= tol are equator columns (pairs without a southern partner).  Returns false if the grid is
 // not symmetric.  Pairs are ordered by their northern row so one operand still streams.
@@ -384,11 +395,7 @@ static bool find_mirror_pairs(const double* lat, int64_t N, std::vector<int>& ro
   // treated as sitting exactly at +-(northern latitude), which perturbs the operator by
   // O(L^2 tol).  The default keeps that below the fp64 parity tolerance; TEMX_SYM_TOL_DEG widens
   // it for grids whose files carry noisier latitudes.
-  double tol = 1e-12;
-  if (const char* e = getenv("TEMX_SYM_TOL_DEG")) {
-    const double t = atof(e);
-    if (t > 0.0 && t < 1e-3) tol = t;
-  }
+  const double tol = sym_tol_deg();
   std::vector<int> north, south, eq;
   for (int64_t i = 0; i < N; ++i) {
     if (!(std::fabs(lat[i]) <= 90.0 + 1e-9)) return false;
@@ -414,6 +421,212 @@ static bool find_mirror_pairs(const double* lat, int64_t N, std::vector<int>& ro
     rowS[k] = pairs[k].second;
   }
   return true;
+}
+
+
+static double sym_tol_deg() {
+  // Two columns share a latitude class (or pair up) when their |lat| agree to within `tol`
+  // degrees; the members are then treated as sitting exactly at the class latitude, which perturbs
+  // the operator by O(L^2 tol).  The default keeps that below the fp64 parity tolerance;
+  // TEMX_SYM_TOL_DEG widens it for grids whose files carry noisier latitudes.
+  double tol = 1e-12;
+  if (const char* e = getenv("TEMX_SYM_TOL_DEG")) {
+    const double t = atof(e);
+    if (t > 0.0 && t < 1e-3) tol = t;
+  }
+  return tol;
+}
+
+// Latitude classes (kernels_cls.hpp).  Returns false when the grid has too few columns per class
+// for the class sweeps to pay (the paired or generic sweeps are used instead).
+struct ClassTables {
+  std::vector<int> crow;        // [nbatch + 2][4][CLS_MB]
+  std::vector<double> xc;       // [4 * (ngroups + 1)] cos(colat) of the class latitude
+  std::vector<int> gbatch0;     // [ngroups + 1]
+  int64_t ncls = 0, ngroups = 0, nbatch = 0;
+};
+
+static bool build_classes(const double* lat, int64_t N, ClassTables& ct) {
+  if (N >= ((int64_t)1 << 28) || N < 64) return false;
+  const double tol = sym_tol_deg();
+  std::vector<int> order((size_t)N);
+  for (int64_t i = 0; i < N; ++i) {
+    if (!(std::fabs(lat[i]) <= 90.0 + 1e-9)) return false;
+    order[(size_t)i] = (int)i;
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs(lat[a]) < std::fabs(lat[b]); });
+  struct Cls {
+    double alat;
+    std::vector<int> n, s;
+  };
+  std::vector<Cls> cls;
+  for (size_t i = 0; i < order.size();) {
+    Cls c;
+    c.alat = std::fabs(lat[order[i]]);
+    size_t j = i;
+    for (; j < order.size() && std::fabs(lat[order[j]]) - c.alat <= tol; ++j) {
+      const int r = order[j];
+      (lat[r] < -tol ? c.s : c.n).push_back(r);      // equator columns count as northern
+    }
+    std::sort(c.n.begin(), c.n.end());
+    std::sort(c.s.begin(), c.s.end());
+    cls.push_back(std::move(c));
+    i = j;
+  }
+  if ((double)N < 3.0 * (double)cls.size()) return false;   // < 3 columns per class: not worth it
+  constexpr int MB = CLS_MB;
+  auto nb = [](size_t m) { return (int)((m + MB - 1) / MB); };
+  // equal member counts inside a class-group; then by first row (some streaming order)
+  std::stable_sort(cls.begin(), cls.end(), [&](const Cls& a, const Cls& b) {
+    const int an = nb(a.n.size()), as = nb(a.s.size()), bn = nb(b.n.size()), bs = nb(b.s.size());
+    if (an != bn) return an > bn;
+    if (as != bs) return as > bs;
+    const int ar = a.n.empty() ? a.s[0] : a.n[0], br = b.n.empty() ? b.s[0] : b.n[0];
+    return ar < br;
+  });
+  ct.ncls = (int64_t)cls.size();
+  ct.ngroups = (ct.ncls + 3) / 4;
+  ct.xc.assign((size_t)(ct.ngroups + 1) * 4, 0.0);
+  ct.gbatch0.assign((size_t)ct.ngroups + 1, 0);
+  ct.crow.clear();
+  const double d2r = M_PI / 180.0;
+  for (int64_t gi = 0; gi < ct.ngroups; ++gi) {
+    int bN = 0, bS = 0;
+    for (int k = 0; k < 4; ++k) {
+      const int64_t ci = gi * 4 + k;
+      if (ci >= ct.ncls) continue;
+      bN = std::max(bN, nb(cls[(size_t)ci].n.size()));
+      bS = std::max(bS, nb(cls[(size_t)ci].s.size()));
+      ct.xc[(size_t)ci] = std::cos((90.0 - cls[(size_t)ci].alat) * d2r);
+    }
+    ct.gbatch0[(size_t)gi] = (int)(ct.crow.size() / (4 * MB));
+    for (int side = 0; side < 2; ++side) {
+      const int nbat = side ? bS : bN;
+      for (int bi = 0; bi < nbat; ++bi) {
+        int flags = side ? CLS_SOUTH : 0;
+        if (bi == 0 && (side == 0 || bN == 0)) flags |= CLS_FIRST;
+        if (bi == nbat - 1 && (side == 1 || bS == 0)) flags |= CLS_LAST;
+        for (int k = 0; k < 4; ++k) {
+          const int64_t ci = gi * 4 + k;
+          for (int j = 0; j < MB; ++j) {
+            const size_t m = (size_t)bi * MB + j;
+            int ent = (int)0x80000000 | (flags << 28);
+            if (ci < ct.ncls) {
+              const std::vector<int>& mem = side ? cls[(size_t)ci].s : cls[(size_t)ci].n;
+              if (m < mem.size()) ent = mem[m] | (flags << 28);
+            }
+            ct.crow.push_back(ent);
+          }
+        }
+      }
+    }
+  }
+  ct.nbatch = (int64_t)(ct.crow.size() / (4 * MB));
+  ct.gbatch0[(size_t)ct.ngroups] = (int)ct.nbatch;
+  ct.crow.resize(ct.crow.size() + 2 * 4 * MB, (int)0x80000000);   // index loads run two batches ahead
+  return true;
+}
+
+// (first batch, first group) of `nsub` pieces of the batch list, cut at group boundaries
+static int class_cuts(temx_plan* pl, int nsub, const int2** out) {
+  auto it = pl->csplits.find(nsub);
+  if (it == pl->csplits.end()) {
+    std::vector<int> cut((size_t)2 * (nsub + 1));
+    int g = 0;
+    for (int k = 0; k <= nsub; ++k) {
+      const int64_t target = pl->cbatches * k / nsub;
+      while (g < pl->cgroups && pl->gbatch0[(size_t)g] < target) ++g;
+      if (k == nsub) g = (int)pl->cgroups;
+      cut[(size_t)2 * k] = pl->gbatch0[(size_t)g];
+      cut[(size_t)2 * k + 1] = g;
+    }
+    DevBuf b;
+    int rc = upload(b, cut.data(), cut.size() * sizeof(int));
+    if (rc) return rc;
+    it = pl->csplits.emplace(nsub, b).first;
+  }
+  *out = static_cast<const int2*>(it->second.p);
+  return TEMX_OK;
+}
+
+constexpr int CLS_PROJ_E_WPS = 3;
+
+template <typename T, int NF>
+static int launch_project_cls_t(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t D, const double* colscale,
+                                int sfield, double* partial, const Split& sp, hipStream_t st) {
+  const int2* cuts = nullptr;
+  if (int rc = class_cuts(pl, sp.nsplit, &cuts)) return rc;
+  dim3 grid(sp.grid), block(256);
+#define TEMX_LPC(TBSv, NFWv, WPSv)                                                                  \
+  hipLaunchKernelGGL((project_cls_kernel<T, NF, NFWv, TBSv, WPSv>), grid, block, 0, st, fp, D, pl->K, \
+                     pl->ycls.d(), static_cast<const int4*>(pl->crow.p), cuts, colscale, sfield,    \
+                     partial, sp.nsplit, sp.ndt)
+  if (NF == 4 && sp.dpw == 1) {     // small ragged D: one d-tile per workgroup, one field per wave
+    switch (pl->TBS) {
+      case 2: TEMX_LPC(2, 1, CLS_PROJ_E_WPS); break;
+      case 4: TEMX_LPC(4, 1, CLS_PROJ_E_WPS); break;
+      case 7: TEMX_LPC(7, 1, CLS_PROJ_E_WPS); break;
+      default: TEMX_LPC(8, 1, CLS_PROJ_E_WPS); break;
+    }
+  } else {
+    switch (pl->TBS) {
+      case 2: TEMX_LPC(2, NF, 2); break;
+      case 4: TEMX_LPC(4, NF, 2); break;
+      case 7: TEMX_LPC(7, NF, 2); break;
+      default: TEMX_LPC(8, NF, 2); break;
+    }
+  }
+#undef TEMX_LPC
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+template <int NF>
+static int launch_project_cls(temx_plan* pl, const FieldPtrs<NF>& fp, int dtype, int64_t D,
+                              const double* colscale, int sfield, double* partial, const Split& sp,
+                              hipStream_t st) {
+  if (dtype == TEMX_F64) return launch_project_cls_t<double, NF>(pl, fp, D, colscale, sfield, partial, sp, st);
+  if (dtype == TEMX_F32) return launch_project_cls_t<float, NF>(pl, fp, D, colscale, sfield, partial, sp, st);
+  return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
+}
+
+template <typename T, int MODE, int DPW, int KIND>
+static int launch_eddy_cls_d(temx_plan* pl, const FieldPtrs<4>& fp, const double* C, double* partial,
+                             const Split& sp, const EddyOut& eo, hipStream_t st) {
+  const int2* cuts = nullptr;
+  if (int rc = class_cuts(pl, sp.nsplit * (8 / DPW), &cuts)) return rc;
+  dim3 grid(sp.grid), block(512);
+  constexpr int NFR = KIND == 0 ? 4 : 3;
+#define TEMX_LEC(TBSv)                                                                                \
+  do {                                                                                                \
+    auto kern = eddy_cls_kernel<T, TBSv, MODE, DPW, KIND>;                                            \
+    const size_t lds = ((size_t)DPW * NFR * 2 * TBSv * 64 + 8 * 2 * TBSv * 16) * sizeof(double);      \
+    static std::atomic<uint64_t> attr_set{0};                                                         \
+    if (int rc_ = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(kern), (int)lds)) \
+      return rc_;                                                                                     \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->D, pl->K, pl->K4, pl->ycls.d(),            \
+                       static_cast<const int4*>(pl->crow.p), cuts, pl->colscale.d(), C, partial,      \
+                       sp.nsplit, sp.ndt, eo);                                                        \
+  } while (0)
+  switch (pl->TBS) {
+    case 2: TEMX_LEC(2); break;
+    case 4: TEMX_LEC(4); break;
+    case 7: TEMX_LEC(7); break;
+    default: TEMX_LEC(8); break;
+  }
+#undef TEMX_LEC
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+template <typename T, int MODE, int KIND>
+static int launch_eddy_cls_t(temx_plan* pl, const FieldPtrs<4>& fp, const double* C, double* partial,
+                             const Split& sp, const EddyOut& eo, hipStream_t st) {
+  switch (sp.dpw) {
+    case 1: return launch_eddy_cls_d<T, MODE, 1, KIND>(pl, fp, C, partial, sp, eo, st);
+    case 2: return launch_eddy_cls_d<T, MODE, 2, KIND>(pl, fp, C, partial, sp, eo, st);
+    default: return launch_eddy_cls_d<T, MODE, 4, KIND>(pl, fp, C, partial, sp, eo, st);
+  }
 }
 
 template <typename T, int NF>
@@ -610,7 +823,9 @@ static void gradient_table(const std::vector<double>& x, std::vector<double>& ta
 }
 
 static inline hipStream_t S_(void* s) { return static_cast<hipStream_t>(s); }
-static inline const Split& eddy_split(const temx_plan* pl) { return pl->sym ? pl->sp_seddy : pl->sp_eddy; }
+static inline const Split& eddy_split(const temx_plan* pl) {
+  return pl->cls ? pl->sp_ceddy : (pl->sym ? pl->sp_seddy : pl->sp_eddy);
+}
 static inline int eddy_slabs(const temx_plan* pl) { return eddy_split(pl).nsplit * (8 / eddy_split(pl).dpw); }
 static inline bool sym_project(const temx_plan* pl, int nf) {   // paired project sweep needs d-quads
   return pl->sym && (nf == 4 ? pl->sp_sproj4.nsplit : pl->sp_sproj1.nsplit) > 0;
@@ -620,6 +835,15 @@ template <int KIND>
 static int run_eddy(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, const double* C, double* partial,
                     const EddyOut* eo, hipStream_t st) {
   EddyOut none{};
+  if (pl->cls) {
+    if (dtype == TEMX_F64)
+      return eo ? launch_eddy_cls_t<double, 1, KIND>(pl, fp, C, partial, pl->sp_ceddy, *eo, st)
+                : launch_eddy_cls_t<double, 0, KIND>(pl, fp, C, partial, pl->sp_ceddy, none, st);
+    if (dtype == TEMX_F32)
+      return eo ? launch_eddy_cls_t<float, 1, KIND>(pl, fp, C, partial, pl->sp_ceddy, *eo, st)
+                : launch_eddy_cls_t<float, 0, KIND>(pl, fp, C, partial, pl->sp_ceddy, none, st);
+    return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
+  }
   if (pl->sym) {
     if (dtype == TEMX_F64)
       return eo ? launch_eddy_sym_t<double, 1, KIND>(pl, fp, C, partial, pl->sp_seddy, *eo, st)
@@ -669,6 +893,9 @@ void temx_plan_destroy(temx_plan* pl) {
                     &pl->B4, &pl->B3, &pl->C4, &pl->zb, &pl->partial, &pl->opB, &pl->opC,
                     &pl->Bq, &pl->Bq2, &pl->Ct, &pl->tz, &pl->rows, &pl->ysym, &pl->Bs, &pl->XB, &pl->P3};
   for (DevBuf* b : bufs) b->release();
+  pl->crow.release();
+  pl->ycls.release();
+  for (auto& kv : pl->csplits) kv.second.release();
   for (int w = 0; w < 2; ++w)
     for (auto& tl : pl->timed[w]) {
       (void)hipEventDestroy(tl.a);
@@ -771,14 +998,45 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return bail(fail(TEMX_EHIP, "gram kernel failed: %s", hipGetErrorString(e)));
   }
-  // mirror pairing (kernels_sym.hpp): ~46 % fewer MFMAs on equatorially symmetric grids
+  {   // blocks of 4 even (or odd) harmonics in the paired / class sweeps
+    const int nhalf = (pl->K + 1) / 2;                         // even harmonics (>= odd ones)
+    const int tbs = (nhalf + 3) / 4;
+    pl->TBS = tbs <= 2 ? 2 : (tbs <= 4 ? 4 : (tbs <= 7 ? 7 : 8));
+  }
+  // latitude classes (kernels_cls.hpp): columns that share |lat| share a basis row -- the MFMA work
+  // is per class and the sweeps become HBM streams (cubed-sphere: 16 columns per class)
   {
+    const char* e0 = getenv("TEMX_NO_SYM");
+    const char* e1 = getenv("TEMX_NO_CLS");
+    ClassTables ct;
+    if (!pl->large && !(flags & (TEMX_NO_SYMMETRY | TEMX_NO_CLASSES)) && !(e0 && e0[0] == '1') &&
+        !(e1 && e1[0] == '1') && build_classes(lat_deg_host, ncol, ct)) {
+      if ((rc = upload(pl->crow, ct.crow.data(), ct.crow.size() * sizeof(int)))) return bail(rc);
+      DevBuf xc;
+      if ((rc = upload(xc, ct.xc.data(), ct.xc.size() * 8))) return bail(rc);
+      rc = pl->ycls.ensure((size_t)(ct.ngroups + 1) * 2 * pl->TBS * 16 * 8);
+      if (rc) {
+        xc.release();
+        return bail(rc);
+      }
+      const int64_t npad = (ct.ngroups + 1) * 4;
+      hipLaunchKernelGGL(cls_basis_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, 0, xc.d(), ct.ncls,
+                         npad, pl->K, pl->TBS, pl->norm.d(), pl->ycls.d());
+      hipError_t e2 = hipDeviceSynchronize();
+      xc.release();
+      if (e2 != hipSuccess) return bail(fail(TEMX_EHIP, "class basis kernel failed: %s", hipGetErrorString(e2)));
+      pl->gbatch0 = std::move(ct.gbatch0);
+      pl->cgroups = ct.ngroups;
+      pl->cbatches = ct.nbatch;
+      pl->ncls = ct.ncls;
+      pl->cls = true;
+    }
+  }
+  // mirror pairing (kernels_sym.hpp): ~46 % fewer MFMAs on equatorially symmetric grids
+  if (!pl->cls) {
     const char* e = getenv("TEMX_NO_SYM");
     std::vector<int> rN, rS;
     if (!pl->large && !(flags & TEMX_NO_SYMMETRY) && !(e && e[0] == '1') && find_mirror_pairs(lat_deg_host, ncol, rN, rS)) {
-      const int nhalf = (pl->K + 1) / 2;                       // even harmonics (>= odd ones)
-      const int tbs = (nhalf + 3) / 4;
-      pl->TBS = tbs <= 2 ? 2 : (tbs <= 4 ? 4 : (tbs <= 7 ? 7 : 8));
       pl->npair = (int64_t)rN.size();
       pl->npg = (pl->npair + 3) / 4;
       pl->npg_alloc = ((pl->npg + SYM_PROJ_CH - 1) / SYM_PROJ_CH + 1) * SYM_PROJ_CH;   // whole chunks + 1 chunk
@@ -806,7 +1064,9 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
   return TEMX_OK;
 }
 
-int temx_plan_is_paired(const temx_plan* pl) { return pl && pl->sym ? 1 : 0; }
+int temx_plan_is_paired(const temx_plan* pl) { return pl && (pl->sym || pl->cls) ? 1 : 0; }
+
+int temx_plan_sweep_mode(const temx_plan* pl) { return !pl ? -1 : (pl->cls ? 2 : (pl->sym ? 1 : 0)); }
 
 int temx_plan_finalize(temx_plan* pl, const double* G_host) {
   if (!pl) return fail(TEMX_EINVAL, "null plan");
@@ -861,6 +1121,8 @@ int temx_plan_set_weights(temx_plan* pl, const double* w_host) {
   std::vector<double> I((size_t)pl->K * pl->K, 0.0);
   for (int k = 0; k < pl->K; ++k) I[(size_t)k * pl->K + k] = 1.0;
   HIPCHK(hipMemcpy(pl->Ginv.p, I.data(), I.size() * 8, hipMemcpyHostToDevice));
+  pl->sym = pl->cls = false;      // weighted rows of one latitude no longer share a basis row
+  pl->tem = false;                // splits / workspaces belong to the path: set_tem again
   pl->finalized = true;
   return TEMX_OK;
 }
@@ -900,11 +1162,18 @@ int temx_project(temx_plan* pl, const void* A, int dtype, int64_t D, double* B, 
   if (!pl || !A || !B) return fail(TEMX_EINVAL, "null argument");
   if (D < 1 || D >= ((int64_t)1 << 28)) return fail(TEMX_EINVAL, "D must be in [1, 2^28)");
   HIPCHK(hipSetDevice(pl->device));
+  FieldPtrs<1> fp;
+  fp.p[0] = A;
+  if (pl->cls) {      // class sweep: one basis row per latitude class
+    Split spc = choose_split(D, pl->cgroups, 2 * pl->num_cu, 4);
+    int rcc = pl->partial.ensure((size_t)spc.nsplit * pl->K * D * 8);
+    if (rcc) return rcc;
+    if ((rcc = launch_project_cls<1>(pl, fp, dtype, D, nullptr, -1, pl->partial.d(), spc, S_(stream)))) return rcc;
+    return launch_reduce(pl, pl->partial.d(), spc.nsplit, (int64_t)pl->K * D, B, S_(stream));
+  }
   Split sp = choose_split(D, pl->nchunk, 2 * pl->num_cu);
   int rc = pl->partial.ensure((size_t)sp.nsplit * std::min(pl->K, 64) * D * 8);
   if (rc) return rc;
-  FieldPtrs<1> fp;
-  fp.p[0] = A;
   return project_all<1>(pl, fp, dtype, D, nullptr, -1, sp, B, S_(stream));
 }
 
@@ -991,6 +1260,15 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
     const size_t need3 = (size_t)pl->sp_proj1.nsplit * 3 * 64 * D * 8;
     if ((rc = pl->partial.ensure(std::max(need3, pl->partial.bytes)))) return rc;
   }
+  if (pl->cls) {
+    const bool quad = pick_dpw(ndt_, 4) == 4;
+    pl->sp_cproj4 = choose_split(D, pl->cgroups, (quad ? 2 : CLS_PROJ_E_WPS) * pl->num_cu, quad ? 4 : 1);
+    pl->sp_cproj1 = choose_split(D, pl->cgroups, 2 * pl->num_cu, 4);
+    pl->sp_ceddy = choose_split(D, pl->cgroups / (8 / edpw), pl->num_cu, edpw);
+    const size_t need3 = (size_t)std::max({pl->sp_cproj4.nsplit * 4, pl->sp_ceddy.nsplit * (8 / edpw) * 3,
+                                           pl->sp_cproj1.nsplit}) * pl->K * D * 8;
+    if ((rc = pl->partial.ensure(std::max(need3, pl->partial.bytes)))) return rc;
+  }
   if (pl->sym) {
     const int64_t nch = (pl->npg + SYM_PROJ_CH - 1) / SYM_PROJ_CH;
     pl->sp_sproj4 = Split();
@@ -1030,12 +1308,13 @@ int temx_tem_stage1(temx_plan* pl, const void* ua, const void* va, const void* t
   TimedLaunch tl{};
   time_begin(pl, 0, st, tl);
   const bool sp4 = sym_project(pl, 4);
-  rc = sp4 ? launch_project_sym<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->partial.d(), pl->sp_sproj4, st)
-           : launch_project<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->partial.d(), pl->sp_proj4, st);
+  const Split& sp = pl->cls ? pl->sp_cproj4 : (sp4 ? pl->sp_sproj4 : pl->sp_proj4);
+  rc = pl->cls ? launch_project_cls<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->partial.d(), sp, st)
+       : sp4   ? launch_project_sym<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->partial.d(), sp, st)
+               : launch_project<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->partial.d(), sp, st);
   time_end(pl, 0, st, tl);
   if (rc) return rc;
-  return launch_reduce(pl, pl->partial.d(), sp4 ? pl->sp_sproj4.nsplit : pl->sp_proj4.nsplit,
-                       (int64_t)4 * pl->K * pl->D, B4, st);
+  return launch_reduce(pl, pl->partial.d(), sp.nsplit, (int64_t)4 * pl->K * pl->D, B4, st);
 }
 
 // ---- large-L (K > 64) second sweep: the fused eddy kernel keeps all coefficients of a d-tile in LDS,
@@ -1161,7 +1440,7 @@ static int tracer_ws(temx_plan* pl) {
   if ((rc = pl->Bq2.ensure((size_t)2 * pl->K * D * 8))) return rc;
   if ((rc = pl->Ct.ensure((size_t)3 * pl->K4 * D * 8))) return rc;
   if ((rc = pl->tz.ensure((size_t)3 * pl->M * D * 8))) return rc;
-  const size_t need = (size_t)pl->sp_proj1.nsplit * pl->K * D * 8;
+  const size_t need = (size_t)std::max(pl->sp_proj1.nsplit, pl->sp_cproj1.nsplit) * pl->K * D * 8;
   return pl->partial.ensure(std::max(need, pl->partial.bytes));
 }
 
@@ -1175,11 +1454,12 @@ int temx_tracer_stage1(temx_plan* pl, const void* q, int dtype, double* Bq, void
   fp.p[0] = q;
   if (pl->large) return project_all<1>(pl, fp, dtype, pl->D, nullptr, -1, pl->sp_proj1, Bq, S_(stream));
   const bool sp1 = sym_project(pl, 1);
-  rc = sp1 ? launch_project_sym<1>(pl, fp, dtype, pl->D, nullptr, -1, pl->partial.d(), pl->sp_sproj1, S_(stream))
-           : launch_project<1>(pl, fp, dtype, pl->D, nullptr, -1, pl->partial.d(), pl->sp_proj1, S_(stream));
+  const Split& sp = pl->cls ? pl->sp_cproj1 : (sp1 ? pl->sp_sproj1 : pl->sp_proj1);
+  rc = pl->cls ? launch_project_cls<1>(pl, fp, dtype, pl->D, nullptr, -1, pl->partial.d(), sp, S_(stream))
+       : sp1   ? launch_project_sym<1>(pl, fp, dtype, pl->D, nullptr, -1, pl->partial.d(), sp, S_(stream))
+               : launch_project<1>(pl, fp, dtype, pl->D, nullptr, -1, pl->partial.d(), sp, S_(stream));
   if (rc) return rc;
-  return launch_reduce(pl, pl->partial.d(), sp1 ? pl->sp_sproj1.nsplit : pl->sp_proj1.nsplit,
-                       (int64_t)pl->K * pl->D, Bq, S_(stream));
+  return launch_reduce(pl, pl->partial.d(), sp.nsplit, (int64_t)pl->K * pl->D, Bq, S_(stream));
 }
 
 int temx_tracer_stage2(temx_plan* pl, const void* q, const void* va, const void* wap, int dtype,

@@ -26,7 +26,7 @@ def _dbl(a):
 class Plan:
     """One plan per (device, native grid, output latitudes, L).  See include/temx.h."""
 
-    def __init__(self, lat_deg, lat_out_deg, L, device=0, defer_finalize=False, symmetry=True):
+    def __init__(self, lat_deg, lat_out_deg, L, device=0, defer_finalize=False, symmetry=True, classes=True):
         self._h = C.c_void_p()
         self.lib = _lib.load()
         if isinstance(device, torch.device):
@@ -40,12 +40,19 @@ class Plan:
         self.nlev = self.nt = self.D = None
         check(self.lib.temx_plan_create(C.byref(self._h), self.device_index, self.N, self.L, self.M,
                                         plat, plat_out, (_lib.DEFER_FINALIZE if defer_finalize else 0)
-                                        | (0 if symmetry else _lib.NO_SYMMETRY)))
+                                        | (0 if symmetry else _lib.NO_SYMMETRY)
+                                        | (0 if classes else _lib.NO_CLASSES)))
 
     @property
     def paired(self):
-        """True when the mirror-paired sweeps are in use (equatorially symmetric grid)."""
+        """True when the sweeps exploit the latitude structure of the grid (mirror-paired or
+        latitude-class sweeps); see :attr:`sweep_mode`."""
         return bool(self.lib.temx_plan_is_paired(self._h))
+
+    @property
+    def sweep_mode(self):
+        """0 generic sweeps, 1 mirror-paired sweeps, 2 latitude-class sweeps."""
+        return int(self.lib.temx_plan_sweep_mode(self._h))
 
     # ---- lifetime ----
     def close(self):

@@ -4,7 +4,8 @@ Two ways the path shards:
 
 * **time sharding** -- the columns of the (N x D) operand are independent, so each rank takes a
   contiguous block of time snapshots with a replicated plan.  No collective on the data path.
-* **ncol sharding** -- rows split in contiguous blocks; the only cross-row reduction is the
+* **ncol sharding** -- rows split in blocks (whole latitude classes per rank, see
+  ``symmetric_ncol_shards``); the only cross-row reduction is the
   projection ``Y0^T A``, so each rank computes partial sums over its rows and the ranks
   all-reduce (i) the K x K Gram matrix once at plan build, (ii) the [4][K][D] sums of
   (u, v, theta, omega) and (iii) the [3][K][D] sums of the eddy products -- one fused message
@@ -31,30 +32,26 @@ def shard_bounds(n, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def symmetric_ncol_shards(lat_deg, world):
-    """Row index sets for ncol sharding that keep every column together with its mirror column
-    (opposite latitude), so each rank's block is itself equatorially symmetric and the engine can
-    use its mirror-paired sweeps.  Falls back to contiguous blocks if the grid is not symmetric.
-    Returns a list of ``world`` int64 index arrays (each sorted ascending)."""
+def symmetric_ncol_shards(lat_deg, world, tol=1e-12):
+    """Row index sets for ncol sharding that keep columns of equal |lat| on one rank: every
+    rank's block then consists of whole latitude classes (a column, its mirror column and all the
+    columns that share their latitude), so the engine can use its latitude-class / mirror-paired
+    sweeps on each rank.  Columns are ordered by |lat| and cut into ``world`` near-equal runs, the
+    cuts moved forward to the next class boundary.  Works for any grid (a grid without repeated
+    latitudes simply gets latitude bands).  Returns ``world`` int64 index arrays, each ascending."""
     import numpy as np
-    lat = np.asarray(lat_deg, dtype=np.float64)
+    lat = np.abs(np.asarray(lat_deg, dtype=np.float64))
     n = lat.size
-    north = np.nonzero(lat > 1e-12)[0]
-    south = np.nonzero(lat < -1e-12)[0]
-    eq = np.nonzero(np.abs(lat) <= 1e-12)[0]
-    ok = north.size == south.size
-    if ok:
-        north = north[np.argsort(lat[north], kind="stable")]
-        south = south[np.argsort(-lat[south], kind="stable")]
-        ok = bool(np.all(np.abs(lat[north] + lat[south]) <= 1e-12))
-    if not ok:
-        return [np.arange(*shard_bounds(n, world, r), dtype=np.int64) for r in range(world)]
-    out = []
-    for r in range(world):
-        p0, p1 = shard_bounds(north.size, world, r)
-        e0, e1 = shard_bounds(eq.size, world, r)
-        out.append(np.sort(np.concatenate([north[p0:p1], south[p0:p1], eq[e0:e1]])).astype(np.int64))
-    return out
+    order = np.argsort(lat, kind="stable")
+    sl = lat[order]
+    cuts = [0]
+    for r in range(1, world):
+        c = max(shard_bounds(n, world, r)[0], cuts[-1])
+        while 0 < c < n and sl[c] - sl[c - 1] <= tol:      # do not cut inside a class
+            c += 1
+        cuts.append(min(c, n))
+    cuts.append(n)
+    return [np.sort(order[cuts[r]:cuts[r + 1]]).astype(np.int64) for r in range(world)]
 
 
 def _world(group=None):

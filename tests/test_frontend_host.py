@@ -99,11 +99,17 @@ def test_symmetric_ncol_shards():
     for p in parts:
         l = np.sort(lat[p])
         assert np.allclose(l, -l[::-1], atol=1e-12)                # each block is mirror symmetric
+        # whole latitude classes: no |lat| value is shared between two blocks
+    al = [np.unique(np.round(np.abs(lat[p]), 9)) for p in parts]
+    assert not (set(al[0]) & set(al[1])) and not (set(al[1]) & set(al[2])) and not (set(al[0]) & set(al[2]))
     sizes = [p.size for p in parts]
-    assert max(sizes) - min(sizes) <= 3
-    # a non-symmetric grid falls back to contiguous blocks
-    parts = sharding.symmetric_ncol_shards(np.linspace(-80, 85, 50), 4)
-    assert [int(p[0]) for p in parts] == [0, 13, 26, 38]
+    assert max(sizes) - min(sizes) <= 32                            # cuts move to class boundaries (<= 16 columns)
+    # a grid without repeated latitudes gets |lat| bands of near-equal size
+    lat2 = np.linspace(-80, 85, 50)
+    parts = sharding.symmetric_ncol_shards(lat2, 4)
+    assert np.array_equal(np.sort(np.concatenate(parts)), np.arange(50))
+    assert [p.size for p in parts] == [13, 13, 12, 12]
+    assert max(np.abs(lat2[parts[0]])) <= min(np.abs(lat2[parts[1]]))
 
 
 def test_format_latlon_data_stacks_lat_major():
