@@ -88,7 +88,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-nt", type=int, default=2)
     ap.add_argument("--no-symmetry", action="store_true",
-                    help="force the generic sweeps (do not use mirror pairing of the symmetric grid)")
+                    help="force the generic sweeps (neither latitude classes nor mirror pairing)")
+    ap.add_argument("--no-classes", action="store_true",
+                    help="do not use the latitude-class sweeps (mirror-paired sweeps on a symmetric grid)")
     ap.add_argument("--no-ncol-extra", action="store_true",
                     help="N > 1, time sharding: skip the extra strong-scaling run of the same job ncol-sharded "
                          "over RCCL (reported as \"ncol_sharded\", not the metric)")
@@ -141,7 +143,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     plan = engine.Plan(lat_l, lat_zm, K_HARM - 1, device=local_rank, defer_finalize=use_ncol,
-                       symmetry=not args.no_symmetry)
+                       symmetry=not args.no_symmetry, classes=not args.no_classes)
     if use_ncol:
         runner = sharding.NcolShardedTEM(plan)
     plan.set_tem(nlev, nt_l, plev * 100)
@@ -195,31 +197,50 @@ def main():
         "config": {"workload": "ne%d (%d cols) x %d lev x %d snapshots per %s, L=50, 1-degree zonal grid (M=180), "
                                "ten GM16 Table-A1 outputs" % (ne, ncol, nlev, nt, "GPU" if scaling == "weak" else "job"),
                    "shard": args.shard if (world > 1 or use_ncol) else "none", "ncol": int(ncol), "nlev": nlev, "nt": nt,
+                   "sweeps": ("generic", "mirror-paired", "latitude-class")[plan.sweep_mode],
                    "mirror_paired_sweeps": bool(plan.paired)},
         "plan_build_s": plan_s,
+        # dense-operator roofline of SURVEY 8(d): max(64 B / 8 TB/s, 1122 flop / 78.6 TF) per point.  The
+        # latitude-class sweeps do the MFMA work per class, not per column, so on grids with repeated
+        # latitudes the pipeline can exceed the MFMA side and is bounded by the two compulsory reads.
         "pipeline_frac_of_fp64_roofline": value / world / (PEAK_F64_TFLOPS * 1e12 / FLOPS_PER_PT),
+        "pipeline_frac_of_hbm_roofline": value / world / (PEAK_HBM_GBS * 1e9 / (8 * (8 if args.dtype == "f64" else 4))),
         "nonfinite": bool(nonfinite),
     }
     if neddy:
         ach = 7 * 2 * K_HARM * pts_rank / (eddy_ms * 1e-3) / 1e12
-        rec["roofline"] = {"kernel": "eddy_kernel (4 reconstructions + eddy products + 3 projections)",
-                           "bound": "mfma", "achieved": ach, "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / PEAK_F64_TFLOPS, "traffic": None, "avg_launch_ms": eddy_ms,
-                           "launches": neddy,
-                           "algorithmic": "7*2*51 flop per grid point x %d points per launch "
-                                          "(the operator's flops; on this equatorially symmetric grid the "
-                                          "mirror-paired sweep executes 54 %% of them)" % pts_rank}
+        if plan.sweep_mode == 2:
+            gbs_e = 4 * esize * pts_rank / (eddy_ms * 1e-3) / 1e9
+            rec["roofline"] = {"kernel": "eddy_cls_kernel (class reconstructions + eddies + products + class projections)",
+                               "bound": "hbm", "achieved": gbs_e, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": gbs_e / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": eddy_ms,
+                               "launches": neddy,
+                               "algorithmic": "4 fields x %d B per grid point (the compulsory read of u, v, T, omega) x %d "
+                                              "points per launch" % (esize, pts_rank),
+                               "operator_tflops": ach,
+                               "note": "operator_tflops = the dense operator's 7*2*51 flop per point over the launch time; "
+                                       "the class sweep executes about 1/8 of them on this grid, which is why the kernel "
+                                       "is HBM bound"}
+        else:
+            rec["roofline"] = {"kernel": "eddy_kernel (4 reconstructions + eddy products + 3 projections)",
+                               "bound": "mfma", "achieved": ach, "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_F64_TFLOPS, "traffic": None, "avg_launch_ms": eddy_ms,
+                               "launches": neddy,
+                               "algorithmic": "7*2*51 flop per grid point x %d points per launch "
+                                              "(the operator's flops; on an equatorially symmetric grid the "
+                                              "mirror-paired sweep executes 54 %% of them)" % pts_rank}
         tr = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tr):
             try:
                 j = json.load(open(tr))
-                if j.get("workload") == args.workload and j.get("dtype") == args.dtype:
+                if (j.get("workload") == args.workload and j.get("dtype") == args.dtype
+                        and j.get("sweeps", "mirror-paired") == rec["config"]["sweeps"]):
                     rec["roofline"]["traffic"] = j.get("eddy_kernel_hbm_bytes_per_launch")
             except Exception:
                 pass
     if nproj:
         gbs = 4 * esize * pts_rank / (proj_ms * 1e-3) / 1e9
-        rec["roofline_project"] = {"kernel": "project_kernel (theta + 4 projections)", "bound": "hbm",
+        rec["roofline_project"] = {"kernel": "project kernel (theta + 4 projections)", "bound": "hbm",
                                    "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": gbs / PEAK_HBM_GBS, "avg_launch_ms": proj_ms,
                                    "mfma_tflops": 4 * 2 * K_HARM * pts_rank / (proj_ms * 1e-3) / 1e12}
@@ -280,7 +301,7 @@ def main():
             torch.cuda.empty_cache()
             mine = sharding.symmetric_ncol_shards(lat, world)[rank]
             p3 = engine.Plan(lat[mine], lat_zm, K_HARM - 1, device=local_rank, defer_finalize=True,
-                             symmetry=not args.no_symmetry)
+                             symmetry=not args.no_symmetry, classes=not args.no_classes)
             runner3 = sharding.NcolShardedTEM(p3)           # all-reduce of the Gram matrix
             p3.set_tem(nlev, nt, plev * 100)
             f3 = engine.synth_fields(local_rank, lat[mine], lon[mine], plev, nt, t0=0, dtype=tdtype, seed=0)
@@ -302,7 +323,7 @@ def main():
                             % (ne, ncol, nlev, nt),
                 "collectives": "2 RCCL all-reduces per step ([4][K][D] and [3][K][D] fp64 = %d bytes) + the "
                                "K x K Gram matrix once at plan build" % (7 * K_HARM * nlev * nt * 8),
-                "mirror_paired_sweeps": bool(p3.paired), "nonfinite": bool(bad3)}
+                "sweeps": ("generic", "mirror-paired", "latitude-class")[p3.sweep_mode], "nonfinite": bool(bad3)}
             p3.close()
         except Exception as e:  # noqa: BLE001 - the metric line must survive a failure of the extra
             rec["ncol_sharded"] = {"error": "%s: %s" % (type(e).__name__, e)}
