@@ -319,7 +319,7 @@ def main():
             rec["ncol_sharded"] = {
                 "scaling": "strong", "value": ncol * nlev * nt * args.steps / e3, "unit": "grid-points/s",
                 "ms_per_step": e3 / args.steps * 1e3, "n_gpus": world,
-                "workload": "ne%d (%d cols) x %d lev x %d snapshots per job, columns sharded in whole mirror pairs"
+                "workload": "ne%d (%d cols) x %d lev x %d snapshots per job, columns sharded in whole latitude classes"
                             % (ne, ncol, nlev, nt),
                 "collectives": "2 RCCL all-reduces per step ([4][K][D] and [3][K][D] fp64 = %d bytes) + the "
                                "K x K Gram matrix once at plan build" % (7 * K_HARM * nlev * nt * 8),

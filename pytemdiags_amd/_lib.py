@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtemx.so")
+LIB_PATH = os.environ.get("TEMX_LIB") or os.path.join(_HERE, "libtemx.so")   # TEMX_LIB: A/B builds
 
 F64, F32 = 0, 1
 DEFER_FINALIZE = 1

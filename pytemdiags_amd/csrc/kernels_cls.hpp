@@ -17,7 +17,7 @@
 //   crow[batch][g][j]  int32: member row j of class g of the batch's group (one int4 per 16-lane
 //                      group), | side << 28 | first-batch-of-group << 29 | last << 30; bit 31 =
 //                      padding (no member: row 0 is read and weighted 0).  Every entry of a batch
-//                      carries the batch flags.  Padded by two batches.
+//                      carries the batch flags.  Padded by CLS_PADB batches.
 //   ycls[group][2*TBS][16]  4x4 blocks at the class latitudes, layout of kernels_sym.hpp's ysym.
 //   csplit[nsub+1]     (first batch, first group) of every piece of work; cuts at group boundaries.
 // No workgroup barriers: each wave stages its own Y blocks (wave-private LDS) and walks its own
@@ -28,6 +28,7 @@
 namespace temx {
 
 constexpr int CLS_MB = 4;                     // member rows per class and batch
+constexpr int CLS_PADB = 5;                   // batches of padding behind crow (index loads run ahead)
 constexpr int CLS_ROWMASK = 0x0FFFFFFF;
 constexpr int CLS_SOUTH = 1, CLS_FIRST = 2, CLS_LAST = 4;   // flags, stored at bit 28
 
@@ -63,7 +64,10 @@ __global__ void cls_basis_kernel(const double* __restrict__ xc, int64_t ncls, in
 // ------------------------------------------------------------------------------------------------
 // class project sweep (sweep 1)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NF, int NFW, int TBS, int WPS>
+// PD = X batches held in registers (PD - 1 in flight while one is consumed); the small one-field-
+// per-wave configuration has the registers for a deeper ring, which is what short batch lists
+// (small D) need: they are latency, not bandwidth, bound.
+template <typename T, int NF, int NFW, int TBS, int WPS, int PD>
 __global__ void __launch_bounds__(256, WPS)
 project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict__ ycls,
                    const int4* __restrict__ crow, const int2* __restrict__ csplit,
@@ -107,9 +111,9 @@ project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
 #pragma unroll
   for (int f = 0; f < NFW; ++f) sN[f] = sS[f] = 0.0;
 
-  T xb[2][MB][NFW];
-  int er[2][MB];
-  int fl[2] = {0, 0};
+  T xb[PD][MB][NFW];
+  int er[PD][MB];
+  int fl[PD];
   double ys[YJ];
   auto load_ys = [&](int gi) __attribute__((always_inline)) {
 #pragma unroll
@@ -129,10 +133,10 @@ project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
   int4 rn;
   auto step = [&](auto pc, int b) __attribute__((always_inline)) {
     constexpr int P = decltype(pc)::value;
-    if (b + 1 < b1) {                         // index load first: it must not queue behind the X loads
+    if (b + (PD - 1) < b1) {                  // index load first: it must not queue behind the X loads
       const int4 r1 = rn;
-      rn = crow[(int64_t)(b + 2) * 4 + g];
-      issue(std::integral_constant<int, P ^ 1>{}, r1);
+      rn = crow[(int64_t)(b + PD) * 4 + g];
+      issue(std::integral_constant<int, (P + PD - 1) % PD>{}, r1);
     }
     const int flags = fl[P];
     double wt[MB];                            // padding entries read row 0 and weigh nothing
@@ -173,13 +177,31 @@ project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
 
   if (b0 < b1) {
     load_ys(grp);
+    // prologue: X of the first PD - 1 batches (the table is padded, a short list just loads padding)
     rn = crow[(int64_t)b0 * 4 + g];
-    const int4 r0 = rn;
-    rn = crow[(int64_t)(b0 + 1) * 4 + g];      // padded: in bounds
-    issue(std::integral_constant<int, 0>{}, r0);
-    for (int b = b0; b < b1; b += 2) {
+    {
+      const int4 r0 = rn;
+      rn = crow[(int64_t)(b0 + 1) * 4 + g];
+      issue(std::integral_constant<int, 0>{}, r0);
+    }
+    if constexpr (PD > 2) {
+      const int4 r0 = rn;
+      rn = crow[(int64_t)(b0 + 2) * 4 + g];
+      if (b0 + 1 < b1) issue(std::integral_constant<int, 1>{}, r0);
+    }
+    if constexpr (PD > 3) {
+      const int4 r0 = rn;
+      rn = crow[(int64_t)(b0 + 3) * 4 + g];
+      if (b0 + 2 < b1) issue(std::integral_constant<int, 2>{}, r0);
+    }
+    for (int b = b0; b < b1; b += PD) {
       step(std::integral_constant<int, 0>{}, b);
-      if (b + 1 < b1) step(std::integral_constant<int, 1>{}, b + 1);
+      if constexpr (PD > 1)
+        if (b + 1 < b1) step(std::integral_constant<int, 1>{}, b + 1);
+      if constexpr (PD > 2)
+        if (b + 2 < b1) step(std::integral_constant<int, 2>{}, b + 2);
+      if constexpr (PD > 3)
+        if (b + 3 < b1) step(std::integral_constant<int, 3>{}, b + 3);
     }
   }
 

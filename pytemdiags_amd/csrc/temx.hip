@@ -134,12 +134,12 @@ static int upload(DevBuf& b, const void* src, size_t bytes) {
 // How to cut (d-tiles x chunk range) into wave-sized work so that `slots` workgroup slots
 // (CUs x resident workgroups) are evenly filled.  Smaller nsplit is preferred on near-ties
 // (fewer partial slabs to write and re-read).
-static Split choose_split(int64_t D, int64_t nchunk, int slots, int dpw = 4) {
+static Split choose_split(int64_t D, int64_t nchunk, int slots, int dpw = 4, int minchunk = 4) {
   Split s;
   s.dpw = dpw;
   s.ndt = (int)((D + 15) / 16);
   const int ndq = (s.ndt + dpw - 1) / dpw;    // a workgroup owns dpw consecutive d-tiles
-  int64_t maxsplit = std::max<int64_t>(1, nchunk / 4);
+  int64_t maxsplit = std::max<int64_t>(1, nchunk / minchunk);
   maxsplit = std::min<int64_t>(maxsplit, std::max<int64_t>(1, (int64_t)4 * slots / ndq + 1));
   maxsplit = std::min<int64_t>(maxsplit, 4096);
   double best = -1.0;
@@ -523,7 +523,7 @@ static bool build_classes(const double* lat, int64_t N, ClassTables& ct) {
   }
   ct.nbatch = (int64_t)(ct.crow.size() / (4 * MB));
   ct.gbatch0[(size_t)ct.ngroups] = (int)ct.nbatch;
-  ct.crow.resize(ct.crow.size() + 2 * 4 * MB, (int)0x80000000);   // index loads run two batches ahead
+  ct.crow.resize(ct.crow.size() + (size_t)CLS_PADB * 4 * MB, (int)0x80000000);   // index loads run ahead
   return true;
 }
 
@@ -549,7 +549,16 @@ static int class_cuts(temx_plan* pl, int nsub, const int2** out) {
   return TEMX_OK;
 }
 
-constexpr int CLS_PROJ_E_WPS = 3;
+#ifndef TEMX_CLS_E_WPS
+#define TEMX_CLS_E_WPS 3
+#endif
+#ifndef TEMX_CLS_E_PD
+#define TEMX_CLS_E_PD 2
+#endif
+#ifndef TEMX_CLS_MINCHUNK
+#define TEMX_CLS_MINCHUNK 4
+#endif
+constexpr int CLS_PROJ_E_WPS = TEMX_CLS_E_WPS, CLS_PROJ_E_PD = TEMX_CLS_E_PD;   // one field per wave
 
 template <typename T, int NF>
 static int launch_project_cls_t(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t D, const double* colscale,
@@ -558,10 +567,10 @@ static int launch_project_cls_t(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t 
   if (int rc = class_cuts(pl, sp.nsplit, &cuts)) return rc;
   dim3 grid(sp.grid), block(256);
 #define TEMX_LPC(TBSv, NFWv, WPSv)                                                                  \
-  hipLaunchKernelGGL((project_cls_kernel<T, NF, NFWv, TBSv, WPSv>), grid, block, 0, st, fp, D, pl->K, \
+  hipLaunchKernelGGL((project_cls_kernel<T, NF, NFWv, TBSv, WPSv, (NFWv == 1 ? CLS_PROJ_E_PD : 2)>), grid, block, 0, st, fp, D, pl->K, \
                      pl->ycls.d(), static_cast<const int4*>(pl->crow.p), cuts, colscale, sfield,    \
                      partial, sp.nsplit, sp.ndt)
-  if (NF == 4 && sp.dpw == 1) {     // small ragged D: one d-tile per workgroup, one field per wave
+  if (NF == 1 || sp.dpw == 1) {     // one field per wave (NF = 4: small ragged D, one d-tile per workgroup)
     switch (pl->TBS) {
       case 2: TEMX_LPC(2, 1, CLS_PROJ_E_WPS); break;
       case 4: TEMX_LPC(4, 1, CLS_PROJ_E_WPS); break;
@@ -1165,7 +1174,7 @@ int temx_project(temx_plan* pl, const void* A, int dtype, int64_t D, double* B, 
   FieldPtrs<1> fp;
   fp.p[0] = A;
   if (pl->cls) {      // class sweep: one basis row per latitude class
-    Split spc = choose_split(D, pl->cgroups, 2 * pl->num_cu, 4);
+    Split spc = choose_split(D, pl->cgroups, CLS_PROJ_E_WPS * pl->num_cu, 4, 1);
     int rcc = pl->partial.ensure((size_t)spc.nsplit * pl->K * D * 8);
     if (rcc) return rcc;
     if ((rcc = launch_project_cls<1>(pl, fp, dtype, D, nullptr, -1, pl->partial.d(), spc, S_(stream)))) return rcc;
@@ -1262,9 +1271,10 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
   }
   if (pl->cls) {
     const bool quad = pick_dpw(ndt_, 4) == 4;
-    pl->sp_cproj4 = choose_split(D, pl->cgroups, (quad ? 2 : CLS_PROJ_E_WPS) * pl->num_cu, quad ? 4 : 1);
-    pl->sp_cproj1 = choose_split(D, pl->cgroups, 2 * pl->num_cu, 4);
-    pl->sp_ceddy = choose_split(D, pl->cgroups / (8 / edpw), pl->num_cu, edpw);
+    // a class-group is already >= 4 batches of rows: pieces may be as short as one group
+    pl->sp_cproj4 = choose_split(D, pl->cgroups, (quad ? 2 : CLS_PROJ_E_WPS) * pl->num_cu, quad ? 4 : 1, TEMX_CLS_MINCHUNK);
+    pl->sp_cproj1 = choose_split(D, pl->cgroups, CLS_PROJ_E_WPS * pl->num_cu, 4, TEMX_CLS_MINCHUNK);
+    pl->sp_ceddy = choose_split(D, pl->cgroups / (8 / edpw), pl->num_cu, edpw, TEMX_CLS_MINCHUNK);
     const size_t need3 = (size_t)std::max({pl->sp_cproj4.nsplit * 4, pl->sp_ceddy.nsplit * (8 / edpw) * 3,
                                            pl->sp_cproj1.nsplit}) * pl->K * D * 8;
     if ((rc = pl->partial.ensure(std::max(need3, pl->partial.bytes)))) return rc;
