@@ -19,7 +19,8 @@
 //                      padding (no member: row 0 is read and weighted 0).  Every entry of a batch
 //                      carries the batch flags.  Padded by CLS_PADB batches.
 //   ycls[group][2*TBS][16]  4x4 blocks at the class latitudes, layout of kernels_sym.hpp's ysym.
-//   csplit[nsub+1]     (first batch, first group) of every piece of work; cuts at group boundaries.
+//   csplit[nsub+1]     (first batch, its group) of every piece of work; equal batch counts, cuts may
+//                      fall inside a group (both sweeps are linear in the member rows).
 // No workgroup barriers: each wave stages its own Y blocks (wave-private LDS) and walks its own
 // flat batch list with the X loads one batch ahead and the row indices two.
 #pragma once
@@ -138,7 +139,7 @@ project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
       rn = crow[(int64_t)(b + PD) * 4 + g];
       issue(std::integral_constant<int, (P + PD - 1) % PD>{}, r1);
     }
-    const int flags = fl[P];
+    const int flags = fl[P] | (b + 1 == b1 ? CLS_LAST : 0);   // a piece may end inside a group: project its partial sums
     double wt[MB];                            // padding entries read row 0 and weigh nothing
 #pragma unroll
     for (int j = 0; j < MB; ++j) wt[j] = er[P][j] < 0 ? 0.0 : 1.0;
@@ -242,9 +243,9 @@ eddy_cls_kernel(FieldPtrs<4> fp, int64_t D, int K, int K4, const double* __restr
   const int w4 = wave % DPW, part = wave / DPW;
   const int c = lane & 15, g = lane >> 4;
   const int dt = dq * DPW + w4;
-  if (dt >= ndt) return;
+  const bool active = dt < ndt;               // waves beyond the ragged end idle up to the final barriers
   const int64_t d = (int64_t)dt * 16 + c;
-  const bool dvalid = d < D;
+  const bool dvalid = active && d < D;
   const int64_t dcl = dvalid ? d : D - 1;
   const int64_t sub = (int64_t)split * NP + part;
   const int b0 = __builtin_amdgcn_readfirstlane(csplit[sub].x);
@@ -252,7 +253,7 @@ eddy_cls_kernel(FieldPtrs<4> fp, int64_t D, int K, int K4, const double* __restr
   int grp = __builtin_amdgcn_readfirstlane(csplit[sub].y);
 
   // coefficient B operands, even blocks then odd blocks: cb[f][tb][lane] = C_f[harm(tb, g)][d]
-  {
+  if (active) {
     double* cb = lds + (size_t)w4 * (NFR * NB * 64) + lane;
 #pragma unroll
     for (int f = 0; f < NFR; ++f) {
@@ -317,7 +318,8 @@ eddy_cls_kernel(FieldPtrs<4> fp, int64_t D, int K, int K4, const double* __restr
       rn = crow[(int64_t)(b + 2) * 4 + g];
       issue(std::integral_constant<int, P ^ 1>{}, r1);
     }
-    const int flags = fl[P];
+    // a piece may begin / end inside a group: reconstruct there, project the partial product sums
+    const int flags = fl[P] | (b == b0 ? CLS_FIRST : 0) | (b + 1 == b1 ? CLS_LAST : 0);
     if (flags & CLS_FIRST) {
       // ---- reconstruction at the class latitudes: E = even-harmonic part, O = odd-harmonic part ----
 #pragma unroll
@@ -409,7 +411,7 @@ eddy_cls_kernel(FieldPtrs<4> fp, int64_t D, int K, int K4, const double* __restr
     }
   };
 
-  if (b0 < b1) {
+  if (active && b0 < b1) {
     load_ys(grp);
     rn = crow[(int64_t)b0 * 4 + g];
     const int4 r0 = rn;
@@ -421,14 +423,34 @@ eddy_cls_kernel(FieldPtrs<4> fp, int64_t D, int K, int K4, const double* __restr
     }
   }
 
-  if (dvalid && partial != nullptr) {
+  if (partial == nullptr) return;             // materialising launch (uniform: same for the whole grid)
+  // ---- the NP waves that split this d-tile's batch range add up in LDS, in a fixed order, so the
+  //      workgroup stores one slab per (split, d-tile) instead of NP
+  __syncthreads();                             // every wave is done with the coefficient slab
+  {
+    double* red = lds + (size_t)w4 * (NFR * NB * 64) + lane;
+    for (int pw = 0; pw < NP; ++pw) {
+      if (part == pw) {
 #pragma unroll
-    for (int q = 0; q < NPR; ++q)
+        for (int q = 0; q < NPR; ++q)
 #pragma unroll
-      for (int tb = 0; tb < NB; ++tb) {
-        const int l = sym_harm<TBS>(tb, g);
-        if (l < K) partial[((sub * NPR + q) * K + l) * D + d] = acc[q][tb];
+          for (int tb = 0; tb < NB; ++tb) {
+            double* r = red + (q * NB + tb) * 64;
+            *r = pw == 0 ? acc[q][tb] : *r + acc[q][tb];
+          }
       }
+      __syncthreads();
+    }
+    if (dvalid) {
+#pragma unroll
+      for (int q = 0; q < NPR; ++q)
+#pragma unroll
+        for (int tb = 0; tb < NB; ++tb) {
+          const int l = sym_harm<TBS>(tb, g);
+          if ((q * NB + tb) % NP == part && l < K)
+            partial[(((int64_t)split * NPR + q) * K + l) * D + d] = red[(q * NB + tb) * 64];
+        }
+    }
   }
 }
 

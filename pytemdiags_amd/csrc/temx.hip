@@ -527,17 +527,17 @@ static bool build_classes(const double* lat, int64_t N, ClassTables& ct) {
   return true;
 }
 
-// (first batch, first group) of `nsub` pieces of the batch list, cut at group boundaries
+// (first batch, its group) of `nsub` pieces of the batch list: equal batch counts; a cut may fall
+// inside a class-group (the sweeps are linear in the member rows, the kernels project partial sums)
 static int class_cuts(temx_plan* pl, int nsub, const int2** out) {
   auto it = pl->csplits.find(nsub);
   if (it == pl->csplits.end()) {
     std::vector<int> cut((size_t)2 * (nsub + 1));
     int g = 0;
     for (int k = 0; k <= nsub; ++k) {
-      const int64_t target = pl->cbatches * k / nsub;
-      while (g < pl->cgroups && pl->gbatch0[(size_t)g] < target) ++g;
-      if (k == nsub) g = (int)pl->cgroups;
-      cut[(size_t)2 * k] = pl->gbatch0[(size_t)g];
+      const int64_t b = pl->cbatches * k / nsub;
+      while (g + 1 < pl->cgroups && pl->gbatch0[(size_t)g + 1] <= b) ++g;
+      cut[(size_t)2 * k] = (int)b;
       cut[(size_t)2 * k + 1] = g;
     }
     DevBuf b;
@@ -556,7 +556,7 @@ static int class_cuts(temx_plan* pl, int nsub, const int2** out) {
 #define TEMX_CLS_E_PD 2
 #endif
 #ifndef TEMX_CLS_MINCHUNK
-#define TEMX_CLS_MINCHUNK 4
+#define TEMX_CLS_MINCHUNK 1
 #endif
 constexpr int CLS_PROJ_E_WPS = TEMX_CLS_E_WPS, CLS_PROJ_E_PD = TEMX_CLS_E_PD;   // one field per wave
 
@@ -835,7 +835,10 @@ static inline hipStream_t S_(void* s) { return static_cast<hipStream_t>(s); }
 static inline const Split& eddy_split(const temx_plan* pl) {
   return pl->cls ? pl->sp_ceddy : (pl->sym ? pl->sp_seddy : pl->sp_eddy);
 }
-static inline int eddy_slabs(const temx_plan* pl) { return eddy_split(pl).nsplit * (8 / eddy_split(pl).dpw); }
+static inline int eddy_slabs(const temx_plan* pl) {   // partial slabs the eddy sweep writes per product
+  if (pl->cls) return pl->sp_ceddy.nsplit;           // the class sweep adds its waves up in LDS first
+  return eddy_split(pl).nsplit * (8 / eddy_split(pl).dpw);
+}
 static inline bool sym_project(const temx_plan* pl, int nf) {   // paired project sweep needs d-quads
   return pl->sym && (nf == 4 ? pl->sp_sproj4.nsplit : pl->sp_sproj1.nsplit) > 0;
 }
@@ -1174,7 +1177,7 @@ int temx_project(temx_plan* pl, const void* A, int dtype, int64_t D, double* B, 
   FieldPtrs<1> fp;
   fp.p[0] = A;
   if (pl->cls) {      // class sweep: one basis row per latitude class
-    Split spc = choose_split(D, pl->cgroups, CLS_PROJ_E_WPS * pl->num_cu, 4, 1);
+    Split spc = choose_split(D, std::max<int64_t>(1, pl->cbatches / 4), CLS_PROJ_E_WPS * pl->num_cu, 4);
     int rcc = pl->partial.ensure((size_t)spc.nsplit * pl->K * D * 8);
     if (rcc) return rcc;
     if ((rcc = launch_project_cls<1>(pl, fp, dtype, D, nullptr, -1, pl->partial.d(), spc, S_(stream)))) return rcc;
@@ -1271,10 +1274,10 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
   }
   if (pl->cls) {
     const bool quad = pick_dpw(ndt_, 4) == 4;
-    // a class-group is already >= 4 batches of rows: pieces may be as short as one group
-    pl->sp_cproj4 = choose_split(D, pl->cgroups, (quad ? 2 : CLS_PROJ_E_WPS) * pl->num_cu, quad ? 4 : 1, TEMX_CLS_MINCHUNK);
-    pl->sp_cproj1 = choose_split(D, pl->cgroups, CLS_PROJ_E_WPS * pl->num_cu, 4, TEMX_CLS_MINCHUNK);
-    pl->sp_ceddy = choose_split(D, pl->cgroups / (8 / edpw), pl->num_cu, edpw, TEMX_CLS_MINCHUNK);
+    const int64_t cunits = std::max<int64_t>(1, pl->cbatches / 4);   // work units of ~4 batches (one cubed-sphere class-group)
+    pl->sp_cproj4 = choose_split(D, cunits, (quad ? 2 : CLS_PROJ_E_WPS) * pl->num_cu, quad ? 4 : 1, TEMX_CLS_MINCHUNK);
+    pl->sp_cproj1 = choose_split(D, cunits, CLS_PROJ_E_WPS * pl->num_cu, 4, TEMX_CLS_MINCHUNK);
+    pl->sp_ceddy = choose_split(D, cunits / (8 / edpw), pl->num_cu, edpw, TEMX_CLS_MINCHUNK);
     const size_t need3 = (size_t)std::max({pl->sp_cproj4.nsplit * 4, pl->sp_ceddy.nsplit * (8 / edpw) * 3,
                                            pl->sp_cproj1.nsplit}) * pl->K * D * 8;
     if ((rc = pl->partial.ensure(std::max(need3, pl->partial.bytes)))) return rc;

@@ -329,3 +329,31 @@ def test_sweep_modes_agree_on_cubed_sphere():
     for o in outs[1:]:
         for i in range(o.shape[0]):
             assert fieldnorm_err(o[i], outs[0][i]) <= 1e-11
+
+
+def test_latlon_grid_tem_vs_oracle():
+    """A structured lat-lon grid (NLON columns per latitude: few, very long latitude classes, so the
+    work cuts fall inside class-groups) through the whole pipeline, eddies included."""
+    from oracle import tem_oracle as orc
+    from pytemdiags_amd import _lib, engine, synth
+    nlat, nlon, nlev, nt, L = 91, 180, 5, 2, 30
+    lat = np.repeat(np.linspace(-90, 90, nlat), nlon)
+    lon = np.tile(np.arange(nlon) * (360.0 / nlon), nlat)
+    plev = synth.pressure_levels(nlev)
+    f = synth.analytic_fields(lat, lon, plev, nt, seed=11)
+    ref = orc.TEMOracle(*f, lat, plev, L=L, mode="factorised")
+    plan = engine.Plan(lat, ref.lat, L)
+    plan.set_tem(nlev, nt, plev * 100)
+    d = [torch.as_tensor(x, device="cuda:0") for x in f]
+    res, zon = plan.tem_run(*d, want_zonal=True)
+    for i, n in enumerate(_lib.RESULT_NAMES):
+        e = fieldnorm_err(res[i].cpu().numpy(), getattr(ref, n)())
+        assert e <= 1e-10, (n, e)
+    for i, n in enumerate(_lib.ZONAL_NAMES):
+        e = fieldnorm_err(zon[i].cpu().numpy(), getattr(ref, n))
+        assert e <= 1e-10, (n, e)
+    ed = plan.tem_eddy(*d)
+    for n in _lib.EDDY_NAMES:
+        assert fieldnorm_err(ed[n].cpu().numpy(), getattr(ref, n)) <= 1e-10, n
+    assert not plan.status()
+    plan.close()
