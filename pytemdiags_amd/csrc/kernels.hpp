@@ -360,6 +360,88 @@ solve_kernel(const double* __restrict__ B, int K, int K4, int M, int64_t D,
 }
 
 // ------------------------------------------------------------------------------------------------
+// solve, K <= 64: C = Ginv . B and Xb = Y0p . C as two small MFMA GEMMs per d-tile.  One wave = one
+// d-tile (16 columns) of one field: the B tile is loaded straight into the MFMA B layout, Ginv and
+// this block's slice of Y0p are staged in LDS as 4x4 blocks (block[k*4+i] = A[4r+i][4t+k], built
+// on the host), the C tile comes out in the B layout and feeds the second product with no lane
+// movement.  gridDim.z slices the output latitudes (16 blocks of 4 per slice); every slice
+// recomputes C (TB*TB MFMAs).
+// ------------------------------------------------------------------------------------------------
+constexpr int SOLVE_MB = 16;          // 4-row blocks of output latitudes per z-slice
+
+template <int TB>
+__global__ void __launch_bounds__(256)
+solve_mfma_kernel(const double* __restrict__ B, int K, int M, int64_t D, const double* __restrict__ gblk,
+                  const double* __restrict__ ypblk, double* __restrict__ C, double* __restrict__ Xb) {
+  extern __shared__ double slds[];          // sg[TB*TB*16], sy[SOLVE_MB*TB*16]
+  double* sg = slds;
+  double* sy = slds + TB * TB * 16;
+  const int f = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int64_t d = ((int64_t)blockIdx.x * 4 + wave) * 16 + c;
+  const bool dvalid = d < D;
+  const int64_t dcl = dvalid ? d : D - 1;
+  const int mb0 = blockIdx.z * SOLVE_MB;
+  const int nmb_all = (M + 3) >> 2;
+  const int nmb = Xb != nullptr ? (nmb_all - mb0 < SOLVE_MB ? nmb_all - mb0 : SOLVE_MB) : 0;
+
+  double breg[TB];
+#pragma unroll
+  for (int t = 0; t < TB; ++t) {            // branch free: clamped row + select
+    const int row = 4 * t + g;
+    const int rc = row < K ? row : K - 1;
+    const double v = B[((int64_t)f * K + rc) * D + dcl];
+    breg[t] = row < K ? v : 0.0;
+  }
+  {   // staging: every global load is issued before the first LDS store (one round trip, not one per element)
+    constexpr int JG = (TB * TB * 16 + 255) / 256, JY = (SOLVE_MB * TB * 16 + 255) / 256;
+    double tg[JG], ty[JY];
+    const double* yp = ypblk + (int64_t)mb0 * TB * 16;
+    const int ny = nmb * TB * 16;
+#pragma unroll
+    for (int j = 0; j < JG; ++j) tg[j] = gblk[tid + 256 * j < TB * TB * 16 ? tid + 256 * j : 0];
+#pragma unroll
+    for (int j = 0; j < JY; ++j) ty[j] = yp[tid + 256 * j < ny ? tid + 256 * j : 0];
+#pragma unroll
+    for (int j = 0; j < JG; ++j)
+      if (tid + 256 * j < TB * TB * 16) sg[tid + 256 * j] = tg[j];
+#pragma unroll
+    for (int j = 0; j < JY; ++j)
+      if (tid + 256 * j < ny) sy[tid + 256 * j] = ty[j];
+  }
+  __syncthreads();
+
+  const uint32_t yoff = (uint32_t)(g * 4 + (lane & 3));
+  double creg[TB];
+#pragma unroll
+  for (int r = 0; r < TB; ++r) creg[r] = 0.0;
+#pragma unroll
+  for (int t = 0; t < TB; ++t)
+#pragma unroll
+    for (int r = 0; r < TB; ++r) creg[r] = TEMX_MFMA4(sg[(r * TB + t) * 16 + yoff], breg[t], creg[r]);
+  if (C != nullptr && blockIdx.z == 0 && dvalid) {
+#pragma unroll
+    for (int r = 0; r < TB; ++r) C[((int64_t)f * (4 * TB) + 4 * r + g) * D + d] = creg[r];
+  }
+  for (int mb = 0; mb < nmb; mb += 4) {     // 4 independent accumulators per pass
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < TB; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int mbj = mb + j < nmb ? mb + j : nmb - 1;
+        acc[j] = TEMX_MFMA4(sy[(mbj * TB + t) * 16 + yoff], creg[t], acc[j]);
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = 4 * (mb0 + mb + j) + g;
+      if (mb + j < nmb && m < M && dvalid) Xb[((int64_t)f * M + m) * D + d] = acc[j];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // eddy / flux sweep (the dominant kernel).  Per step (8 columns) x d-tile (16), one wave:
 //   xbar_f = Y0[chunk] . C_f                (4 reconstructions; contraction over harmonics)
 //            = sph_zonal_mean_native of tem_diagnostics.py:517-529, never stored

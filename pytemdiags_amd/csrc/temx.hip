@@ -90,6 +90,7 @@ struct temx_plan {
   bool finalized = false;
   int rank = 0;               // numerical rank of Y0 (== K unless the pseudo-inverse fallback ran)
   DevBuf x, Y0, yblk, yblk_w, Y0p, G, Ginv, norm, flag;
+  DevBuf gblk, ypblk;            // Ginv / Y0p as 4x4 MFMA A-operand blocks (solve_mfma_kernel, K <= 64)
   const double* yproj_ptr() const { return yblk_w.p ? yblk_w.d() : yblk.d(); }
   std::vector<double> lat_out_deg;
   // TEM configuration
@@ -168,6 +169,30 @@ static int lds_attr_once(std::atomic<uint64_t>& done, int device, const void* fn
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   done.fetch_or(bit, std::memory_order_release);
   return TEMX_OK;
+}
+
+
+// 4x4 MFMA A-operand blocks of a row-major R x K matrix: blk[rb][t][k*4+i] = A[4rb+i][4t+k], zero padded
+static int upload_blocks(DevBuf& dst, const double* A, int R, int K, int TB) {
+  const int nrb = (R + 3) / 4;
+  std::vector<double> blk((size_t)nrb * TB * 16, 0.0);
+  for (int rb = 0; rb < nrb; ++rb)
+    for (int t = 0; t < TB; ++t)
+      for (int k = 0; k < 4; ++k)
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * rb + i, col = 4 * t + k;
+          if (r < R && col < K) blk[((size_t)rb * TB + t) * 16 + k * 4 + i] = A[(size_t)r * K + col];
+        }
+  return upload(dst, blk.data(), blk.size() * 8);
+}
+
+static int set_ginv(temx_plan* pl, const double* Gi_host) {
+  HIPCHK(hipMemcpy(pl->Ginv.p, Gi_host, (size_t)pl->K * pl->K * 8, hipMemcpyHostToDevice));
+  if (pl->K > 64) return TEMX_OK;
+  // Ginv padded to 4*TB rows: upload_blocks wants TB row-blocks
+  std::vector<double> Gp((size_t)4 * pl->TB * pl->K, 0.0);
+  std::copy(Gi_host, Gi_host + (size_t)pl->K * pl->K, Gp.begin());
+  return upload_blocks(pl->gblk, Gp.data(), 4 * pl->TB, pl->K, pl->TB);
 }
 
 static void time_begin(temx_plan* pl, int which, hipStream_t st, TimedLaunch& tl) {
@@ -275,19 +300,33 @@ static int launch_reduce(temx_plan* pl, const double* partial, int nsplit, int64
 
 static int launch_solve(temx_plan* pl, const double* B, int NF, int64_t D, double* C, double* Xb,
                         hipStream_t st) {
+  if (pl->K <= 64) {   // two small MFMA GEMMs per d-tile
+    const int nmb = (pl->M + 3) / 4;
+    dim3 grid((unsigned)(((D + 15) / 16 + 3) / 4), NF, Xb ? (nmb + SOLVE_MB - 1) / SOLVE_MB : 1);
+#define TEMX_LS(TBv)                                                                                  \
+  do {                                                                                                \
+    const size_t slds = ((size_t)TBv * TBv + (size_t)SOLVE_MB * TBv) * 16 * sizeof(double);           \
+    static std::atomic<uint64_t> attr{0};                                                             \
+    if (int rc_ = lds_attr_once(attr, pl->device, reinterpret_cast<const void*>(solve_mfma_kernel<TBv>), (int)slds)) \
+      return rc_;                                                                                     \
+    hipLaunchKernelGGL(solve_mfma_kernel<TBv>, grid, dim3(256), slds, st, B, pl->K, pl->M, D,         \
+                       pl->gblk.d(), pl->ypblk.d(), C, Xb);                                           \
+  } while (0)
+    switch (pl->TB) {
+      case 4: TEMX_LS(4); break;
+      case 8: TEMX_LS(8); break;
+      case 13: TEMX_LS(13); break;
+      default: TEMX_LS(16); break;
+    }
+#undef TEMX_LS
+    HIPCHK(hipGetLastError());
+    return TEMX_OK;
+  }
   // 16 waves per block (the solve is latency bound: one round of dot products per phase); slices of
   // 64 output latitudes = one zonal-mean output per thread
   const int ms = Xb ? (pl->M + 63) / 64 : 1;
   dim3 grid((unsigned)((D + 15) / 16), NF, ms);
-  const int mper = (pl->M + ms - 1) / ms;
-  if (pl->K <= 64) {
-    const size_t slds = ((size_t)2 * pl->K4 * 17 + (size_t)pl->K * pl->K + (Xb ? (size_t)mper * pl->K : 0)) * sizeof(double);
-    static std::atomic<uint64_t> attr{0};
-    if (int rc = lds_attr_once(attr, pl->device, reinterpret_cast<const void*>(solve_kernel<true>), 160 * 1024)) return rc;
-    if (slds > 160 * 1024) return fail(TEMX_EUNSUPPORTED, "M = %d output latitudes: solve staging exceeds LDS", pl->M);
-    hipLaunchKernelGGL(solve_kernel<true>, grid, dim3(1024), slds, st, B, pl->K, pl->K4, pl->M, D, pl->Ginv.d(),
-                       pl->Y0p.d(), C, Xb);
-  } else {
+  {
     const size_t slds = (size_t)2 * pl->K4 * 17 * sizeof(double);
     static std::atomic<uint64_t> attr{0};
     if (int rc = lds_attr_once(attr, pl->device, reinterpret_cast<const void*>(solve_kernel<false>), 160 * 1024)) return rc;
@@ -907,6 +946,8 @@ void temx_plan_destroy(temx_plan* pl) {
   for (DevBuf* b : bufs) b->release();
   pl->crow.release();
   pl->ycls.release();
+  pl->gblk.release();
+  pl->ypblk.release();
   for (auto& kv : pl->csplits) kv.second.release();
   for (int w = 0; w < 2; ++w)
     for (auto& tl : pl->timed[w]) {
@@ -996,6 +1037,12 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
     hipError_t e = hipDeviceSynchronize();
     xo.release();
     if (e != hipSuccess) return bail(fail(TEMX_EHIP, "basis kernel failed: %s", hipGetErrorString(e)));
+    if (pl->K <= 64) {   // blocked copy for solve_mfma_kernel
+      std::vector<double> yp((size_t)M * pl->K);
+      if (hipMemcpy(yp.data(), pl->Y0p.p, yp.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        return bail(fail(TEMX_EHIP, "copy of Y0p failed"));
+      if ((rc = upload_blocks(pl->ypblk, yp.data(), M, pl->K, pl->TB))) return bail(rc);
+    }
   }
 
   // local Gram G = Y0^T Y0 through the projection sweep itself (A = Y0, D = K)
@@ -1102,7 +1149,7 @@ int temx_plan_finalize(temx_plan* pl, const double* G_host) {
   } else {
     pl->rank = K;
   }
-  HIPCHK(hipMemcpy(pl->Ginv.p, Gi.data(), Gi.size() * 8, hipMemcpyHostToDevice));
+  if (int rcg = set_ginv(pl, Gi.data())) return rcg;
   int zero = 0;
   HIPCHK(hipMemcpy(pl->flag.p, &zero, sizeof(int), hipMemcpyHostToDevice));
   pl->finalized = true;
@@ -1132,7 +1179,7 @@ int temx_plan_set_weights(temx_plan* pl, const double* w_host) {
   if (e != hipSuccess) return fail(TEMX_EHIP, "basis kernel failed: %s", hipGetErrorString(e));
   std::vector<double> I((size_t)pl->K * pl->K, 0.0);
   for (int k = 0; k < pl->K; ++k) I[(size_t)k * pl->K + k] = 1.0;
-  HIPCHK(hipMemcpy(pl->Ginv.p, I.data(), I.size() * 8, hipMemcpyHostToDevice));
+  if (int rcg = set_ginv(pl, I.data())) return rcg;
   pl->sym = pl->cls = false;      // weighted rows of one latitude no longer share a basis row
   pl->tem = false;                // splits / workspaces belong to the path: set_tem again
   pl->finalized = true;
