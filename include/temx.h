@@ -91,9 +91,15 @@ int temx_device_count(void);
  * lat_deg_host[ncol], lat_out_deg_host[M] in degrees.  L <= 511.  Up to L = 63 (K <= 64) the TEM
  * sweeps are the fused kernels; larger L runs the same pipeline as 64-harmonic slices (sliced
  * projections, accumulating native reconstructions, an elementwise eddy-product pass).
- * If every column has a mirror column at the opposite latitude (cubed-sphere, lat-lon, Gaussian
- * grids) the TEM sweeps run in a mirror-paired form that needs ~54 % of the matrix work (same
- * operator, results equal up to rounding); flags & TEMX_NO_SYMMETRY or TEMX_NO_SYM=1 disables it. */
+ * The sweeps come in three forms, chosen here from the latitudes alone (same operator, results equal
+ * up to rounding; temx_plan_sweep_mode tells which):
+ *   latitude-class  columns that share |lat| share a basis row (cubed-sphere: 16 per class, lat-lon:
+ *                   2 NLON): member rows are added, the matrix work is done once per class and the
+ *                   sweeps are HBM streams.  Used when the grid has >= 3 columns per class;
+ *                   TEMX_NO_CLASSES / TEMX_NO_CLS=1 disables.
+ *   mirror-paired   every column has a mirror column at the opposite latitude: 54 % of the matrix work.
+ *   generic         any grid.  TEMX_NO_SYMMETRY / TEMX_NO_SYM=1 forces it.
+ * Latitudes are matched to within 1e-12 degrees (TEMX_SYM_TOL_DEG in the environment widens that). */
 int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
                      const double* lat_deg_host, const double* lat_out_deg_host, int flags);
 

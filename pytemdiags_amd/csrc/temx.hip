@@ -1328,6 +1328,10 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
     const size_t need3 = (size_t)std::max({pl->sp_cproj4.nsplit * 4, pl->sp_ceddy.nsplit * (8 / edpw) * 3,
                                            pl->sp_cproj1.nsplit}) * pl->K * D * 8;
     if ((rc = pl->partial.ensure(std::max(need3, pl->partial.bytes)))) return rc;
+    // work cuts now, not at the first launch: launches must stay legal inside a stream capture
+    const int2* cuts_unused = nullptr;
+    for (int nsub : {pl->sp_cproj4.nsplit, pl->sp_cproj1.nsplit, pl->sp_ceddy.nsplit * (8 / edpw)})
+      if ((rc = class_cuts(pl, nsub, &cuts_unused))) return rc;
   }
   if (pl->sym) {
     const int64_t nch = (pl->npg + SYM_PROJ_CH - 1) / SYM_PROJ_CH;

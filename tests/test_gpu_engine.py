@@ -193,3 +193,30 @@ def test_zonal_mean_large_L_vs_oracle(eng, L):
     assert fieldnorm_err(z32, Z.zonal_mean(A)) <= TOL32
     assert not plan.status()
     plan.close()
+
+
+def test_sweep_form_is_chosen_from_the_latitudes(eng):
+    """temx_plan_create picks latitude-class, mirror-paired or generic sweeps from the grid alone."""
+    from pytemdiags_amd import synth
+    rng = np.random.default_rng(3)
+    lat_out = np.linspace(-80, 80, 17)
+    nosym = os.environ.get("TEMX_NO_SYM") == "1"
+    nocls = nosym or os.environ.get("TEMX_NO_CLS") == "1"
+    cases = [
+        (synth.cubed_sphere_gll(6)[0], 2),                                  # 16 columns per |lat|
+        (np.repeat(np.linspace(-87, 87, 30), 24), 2),                       # lat-lon
+        (np.concatenate([a := rng.uniform(1, 89, 500), -a]), 1),            # mirror symmetric, distinct latitudes
+        (rng.uniform(-89, 89, 1000), 0),                                    # no structure
+        (np.concatenate([b := np.linspace(2, 85, 20), -b]), 1),               # small symmetric grid: pairs
+        (np.repeat(np.linspace(-80, 80, 9), 5), 1),                         # < 64 columns: no classes, but pairs
+    ]
+    for lat, want in cases:
+        lat = np.array(lat)
+        rng.shuffle(lat)
+        plan = eng.Plan(lat, lat_out, 12)
+        expect = 0 if nosym else (min(want, 1) if nocls else want)
+        if want == 2 and nocls and not nosym:
+            expect = 1                                                      # both example grids are mirror symmetric
+        assert plan.sweep_mode == expect, (lat.size, want, plan.sweep_mode)
+        assert plan.paired == (expect > 0)
+        plan.close()
