@@ -28,6 +28,14 @@
 
 namespace temx {
 
+// X is read once per sweep.  Non-temporal loads (-DTEMX_NT_LOADS) were measured: +2 % on ne120x72x30
+// (6.0 TB/s) but -20 % on the ne30 shapes, so plain loads stay the default.
+#ifdef TEMX_NT_LOADS
+#define TEMX_XLOAD(p) __builtin_nontemporal_load(p)
+#else
+#define TEMX_XLOAD(p) (*(p))
+#endif
+
 constexpr int CLS_MB = 4;                     // member rows per class and batch
 constexpr int CLS_PADB = 5;                   // batches of padding behind crow (index loads run ahead)
 constexpr int CLS_ROWMASK = 0x0FFFFFFF;
@@ -128,7 +136,7 @@ project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
     for (int j = 0; j < MB; ++j) {
       const int64_t off = (int64_t)(er[P][j] & CLS_ROWMASK) * D;
 #pragma unroll
-      for (int f = 0; f < NFW; ++f) xb[P][j][f] = fb[f][off];
+      for (int f = 0; f < NFW; ++f) xb[P][j][f] = TEMX_XLOAD(fb[f] + off);
     }
   };
   int4 rn;
@@ -307,7 +315,7 @@ eddy_cls_kernel(FieldPtrs<4> fp, int64_t D, int K, int K4, const double* __restr
     for (int j = 0; j < MB; ++j) {
       const int64_t off = (int64_t)(er[P][j] & CLS_ROWMASK) * D;
 #pragma unroll
-      for (int f = 0; f < NFR; ++f) xb[P][j][f] = fb[f][off];
+      for (int f = 0; f < NFR; ++f) xb[P][j][f] = TEMX_XLOAD(fb[f] + off);
     }
   };
   int4 rn;
