@@ -139,3 +139,26 @@ def test_format_latlon_data_stacks_lat_major():
     bad = dict(data, lat_bnds=LabeledArray(np.zeros((3, 2)), ("lat", "bnds")))
     with pytest.raises(RuntimeError, match="does not have dimension nbnd"):
         format_latlon_data(bad)
+
+
+def test_c_abi_header_is_plain_c_and_links(tmp_path):
+    """include/temx.h compiles as C and every entry point resolves against libtemx.so from a C program."""
+    import shutil
+    import subprocess
+    from pytemdiags_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "link_check")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c_abi", "link_check.c"), "-o", exe,
+                    "-L", libdir, "-ltemx", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "temx_version=100" in out.stdout and "null_plan_rc=-1" in out.stdout
+    # the header declares exactly what the ctypes table binds
+    hdr = open(os.path.join(root, "include", "temx.h")).read()
+    import re
+    declared = set(re.findall(r"\b(temx_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == {n for n, _, _ in _lib.SIGNATURES}
