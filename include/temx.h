@@ -119,6 +119,12 @@ int temx_plan_is_paired(const temx_plan* plan);
 /* 0 generic sweeps, 1 mirror-paired sweeps, 2 latitude-class sweeps (columns that share |lat| share a
  * basis row: cubed-sphere, lat-lon and Gaussian grids; TEMX_NO_CLS=1 in the environment disables) */
 int temx_plan_sweep_mode(const temx_plan* plan);
+/* 1 when (after temx_plan_set_tem) the latitude-class path runs in its one-pass form: sweep 1 also
+ * stores per-class sums of u v, u omega, v theta, and the eddy-product sums of a class follow
+ * algebraically from them (the zonal mean is constant inside a class side), so temx_tem_stage2 does
+ * not read the fields again.  Needs quads of d-tiles (nlev*nt not tiny) and workspace of 14 x 512 B
+ * per class-group and d-tile; TEMX_TWO_PASS=1 in the environment disables. */
+int temx_plan_one_pass(const temx_plan* plan);
 
 int temx_get_matrix(temx_plan* plan, int which, double* dst, void* stream);
 

@@ -76,12 +76,18 @@ __global__ void cls_basis_kernel(const double* __restrict__ xc, int64_t ncls, in
 // PD = X batches held in registers (PD - 1 in flight while one is consumed); the small one-field-
 // per-wave configuration has the registers for a deeper ring, which is what short batch lists
 // (small D) need: they are latency, not bandwidth, bound.
-template <typename T, int NF, int NFW, int TBS, int WPS, int PD>
+// OP ("one pass", NF = NFW = 4 only): the sweep also accumulates, per class and side, the sums of u v,
+// u omega and v T next to the four field sums and stores the 7 x 2 sums of every (class-group,
+// d-tile) in csum: with them flux_cls_kernel gets the eddy-product sums of a class algebraically
+// (x-bar is constant inside a class side), so the fields are read ONCE.  Needs work cuts at group
+// boundaries.
+template <typename T, int NF, int NFW, int TBS, int WPS, int PD, bool OP>
 __global__ void __launch_bounds__(256, WPS)
 project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict__ ycls,
                    const int4* __restrict__ crow, const int2* __restrict__ csplit,
                    const double* __restrict__ colscale, int sfield, double* __restrict__ partial, int nsplit,
-                   int ndt) {
+                   int ndt, double* __restrict__ csum) {
+  static_assert(!OP || (NF == 4 && NFW == 4), "one-pass sums need all four fields in one wave");
   constexpr int DPW = 4 * NFW / NF;
   constexpr int NB = 2 * TBS;
   constexpr int YE = NB * 16;
@@ -119,6 +125,7 @@ project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
   double sN[NFW], sS[NFW];
 #pragma unroll
   for (int f = 0; f < NFW; ++f) sN[f] = sS[f] = 0.0;
+  double qN[3] = {0.0, 0.0, 0.0}, qS[3] = {0.0, 0.0, 0.0};   // OP: sums of u v, u omega, v T
 
   T xb[PD][MB][NFW];
   int er[PD][MB];
@@ -151,7 +158,22 @@ project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
     double wt[MB];                            // padding entries read row 0 and weigh nothing
 #pragma unroll
     for (int j = 0; j < MB; ++j) wt[j] = er[P][j] < 0 ? 0.0 : 1.0;
-    if (flags & CLS_SOUTH) {
+    if constexpr (OP) {
+      double* sx = (flags & CLS_SOUTH) ? sS : sN;
+      double* sq = (flags & CLS_SOUTH) ? qS : qN;
+#pragma unroll
+      for (int j = 0; j < MB; ++j) {
+        const double u = wt[j] * (double)xb[P][j][0], v = wt[j] * (double)xb[P][j][1];
+        const double tt = (double)xb[P][j][2], om = (double)xb[P][j][3];
+        sx[0] += u;
+        sx[1] += v;
+        sx[2] += wt[j] * tt;
+        sx[3] += wt[j] * om;
+        sq[0] += u * (double)xb[P][j][1];
+        sq[1] += u * om;
+        sq[2] += v * tt;
+      }
+    } else if (flags & CLS_SOUTH) {
 #pragma unroll
       for (int j = 0; j < MB; ++j)
 #pragma unroll
@@ -166,6 +188,24 @@ project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
 #pragma unroll
       for (int j = 0; j < YJ; ++j)
         if (lane + 64 * j < YE) yst[lane + 64 * j] = ys[j];
+      if constexpr (OP) {                     // 7 sums per side of this (group, d-tile), theta-scaled
+        if (dvalid) {
+          double* o = csum + (((int64_t)grp * ndt + dt) * 14) * 64 + lane;
+#pragma unroll
+          for (int f = 0; f < 4; ++f) {
+            o[f * 64] = sN[f] * sc[f];
+            o[(7 + f) * 64] = sS[f] * sc[f];
+          }
+          o[4 * 64] = qN[0];
+          o[5 * 64] = qN[1];
+          o[6 * 64] = qN[2] * sc[2];
+          o[11 * 64] = qS[0];
+          o[12 * 64] = qS[1];
+          o[13 * 64] = qS[2] * sc[2];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) qN[q] = qS[q] = 0.0;
+      }
       ++grp;
       load_ys(grp);                           // ycls is padded by one group
       double ss[NFW], dd[NFW];
@@ -435,6 +475,151 @@ eddy_cls_kernel(FieldPtrs<4> fp, int64_t D, int K, int K4, const double* __restr
   // ---- the NP waves that split this d-tile's batch range add up in LDS, in a fixed order, so the
   //      workgroup stores one slab per (split, d-tile) instead of NP
   __syncthreads();                             // every wave is done with the coefficient slab
+  {
+    double* red = lds + (size_t)w4 * (NFR * NB * 64) + lane;
+    for (int pw = 0; pw < NP; ++pw) {
+      if (part == pw) {
+#pragma unroll
+        for (int q = 0; q < NPR; ++q)
+#pragma unroll
+          for (int tb = 0; tb < NB; ++tb) {
+            double* r = red + (q * NB + tb) * 64;
+            *r = pw == 0 ? acc[q][tb] : *r + acc[q][tb];
+          }
+      }
+      __syncthreads();
+    }
+    if (dvalid) {
+#pragma unroll
+      for (int q = 0; q < NPR; ++q)
+#pragma unroll
+        for (int tb = 0; tb < NB; ++tb) {
+          const int l = sym_harm<TBS>(tb, g);
+          if ((q * NB + tb) % NP == part && l < K)
+            partial[(((int64_t)split * NPR + q) * K + l) * D + d] = red[(q * NB + tb) * 64];
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// flux_cls_kernel: second phase of the one-pass class path.  Per (class-group, d-tile): reconstruct
+// the zonal means at the class latitudes (4 x 14 MFMAs), turn the stored class sums into the sums
+// of the eddy products --
+//     sum (u - ub)(v - vb) = S_uv - vb S_u - ub S_v + n ub vb       (ub, vb constant in a class side)
+// -- and project them (3 x 14 MFMAs).  Reads 14 x 512 B per (group, d-tile) instead of the fields.
+// ------------------------------------------------------------------------------------------------
+template <int TBS, int DPW>
+__global__ void __launch_bounds__(512, 2)
+flux_cls_kernel(int64_t D, int K, int K4, const double* __restrict__ ycls, const double* __restrict__ csum,
+                const double* __restrict__ ccnt, int64_t ngroups, const double* __restrict__ C,
+                double* __restrict__ partial, int nsplit, int ndt) {
+  extern __shared__ double lds[];
+  constexpr int NB = 2 * TBS;
+  constexpr int YE = NB * 16;
+  constexpr int YJ = (YE + 63) / 64;
+  constexpr int NP = 8 / DPW;
+  constexpr int NFR = 4, NPR = 3;
+  int split, dq;
+  if (!wg_work((ndt + DPW - 1) / DPW, nsplit, split, dq)) return;
+  const int wave = uniform_wave(), lane = threadIdx.x & 63;
+  const int w4 = wave % DPW, part = wave / DPW;
+  const int c = lane & 15, g = lane >> 4;
+  const int dt = dq * DPW + w4;
+  const bool active = dt < ndt;
+  const int64_t d = (int64_t)dt * 16 + c;
+  const bool dvalid = active && d < D;
+  const int64_t dcl = dvalid ? d : D - 1;
+  const int64_t sub = (int64_t)split * NP + part, nsub = (int64_t)nsplit * NP;
+  const int g0 = (int)(ngroups * sub / nsub), g1 = (int)(ngroups * (sub + 1) / nsub);
+
+  if (active) {
+    double* cb = lds + (size_t)w4 * (NFR * NB * 64) + lane;
+#pragma unroll
+    for (int f = 0; f < NFR; ++f) {
+      double v[NB];
+#pragma unroll
+      for (int tb = 0; tb < NB; ++tb) {
+        const int l = sym_harm<TBS>(tb, g);
+        const int lc = l < K ? l : K - 1;
+        v[tb] = C[((int64_t)f * K4 + lc) * D + dcl];
+      }
+#pragma unroll
+      for (int tb = 0; tb < NB; ++tb) cb[(f * NB + tb) * 64] = sym_harm<TBS>(tb, g) < K ? v[tb] : 0.0;
+    }
+  }
+  int cbi = w4 * (NFR * NB * 64) + lane;
+  double* yst = lds + DPW * NFR * NB * 64 + wave * YE;
+  const uint32_t aoff_r = (uint32_t)((lane & 3) * 4 + g);
+  const uint32_t aoff_p = (uint32_t)(g * 4 + (lane & 3));
+
+  double acc[NPR][NB];
+#pragma unroll
+  for (int q = 0; q < NPR; ++q)
+#pragma unroll
+    for (int t = 0; t < NB; ++t) acc[q][t] = 0.0;
+
+  double sv[2][14], cn[2][2], ys[2][YJ];
+  auto load = [&](auto pc, int gi) __attribute__((always_inline)) {
+    constexpr int P = decltype(pc)::value;
+    const double* base = csum + (((int64_t)gi * ndt + (active ? dt : 0)) * 14) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < YJ; ++j) ys[P][j] = (ycls + (int64_t)gi * YE)[(lane + 64 * j) < YE ? (lane + 64 * j) : 0];
+    cn[P][0] = ccnt[(int64_t)gi * 8 + g];
+    cn[P][1] = ccnt[(int64_t)gi * 8 + 4 + g];
+#pragma unroll
+    for (int s_ = 0; s_ < 14; ++s_) sv[P][s_] = base[s_ * 64];
+  };
+  auto step = [&](auto pc, int gi) __attribute__((always_inline)) {
+    constexpr int P = decltype(pc)::value;
+    if (gi + 1 < g1) load(std::integral_constant<int, P ^ 1>{}, gi + 1);
+#pragma unroll
+    for (int j = 0; j < YJ; ++j)
+      if (lane + 64 * j < YE) yst[lane + 64 * j] = ys[P][j];
+    asm volatile("" : "+v"(cbi));
+    const double* cbr = lds + cbi;
+    double E[NFR], O[NFR];
+#pragma unroll
+    for (int f = 0; f < NFR; ++f) E[f] = O[f] = 0.0;
+#pragma unroll
+    for (int tb = 0; tb < NB; ++tb) {
+      const double ya = yst[tb * 16 + aoff_r];
+#pragma unroll
+      for (int f = 0; f < NFR; ++f) {
+        if (tb < TBS)
+          E[f] = TEMX_MFMA4(ya, cbr[(f * NB + tb) * 64], E[f]);
+        else
+          O[f] = TEMX_MFMA4(ya, cbr[(f * NB + tb) * 64], O[f]);
+      }
+    }
+    double pr[2][NPR];
+#pragma unroll
+    for (int sd = 0; sd < 2; ++sd) {
+      const double* S = sv[P] + 7 * sd;
+      const double n = cn[P][sd];
+      const double ub = sd ? E[0] - O[0] : E[0] + O[0], vb = sd ? E[1] - O[1] : E[1] + O[1];
+      const double tb_ = sd ? E[2] - O[2] : E[2] + O[2], wb = sd ? E[3] - O[3] : E[3] + O[3];
+      pr[sd][0] = S[4] - vb * S[0] - ub * S[1] + n * ub * vb;      // u'v'
+      pr[sd][1] = S[5] - wb * S[0] - ub * S[3] + n * ub * wb;      // u'omega'
+      pr[sd][2] = S[6] - tb_ * S[1] - vb * S[2] + n * vb * tb_;    // v'theta'
+    }
+#pragma unroll
+    for (int tb = 0; tb < NB; ++tb) {
+      const double ya = yst[tb * 16 + aoff_p];
+#pragma unroll
+      for (int q = 0; q < NPR; ++q)
+        acc[q][tb] = TEMX_MFMA4(ya, tb < TBS ? pr[0][q] + pr[1][q] : pr[0][q] - pr[1][q], acc[q][tb]);
+    }
+  };
+  if (active && g0 < g1) {
+    load(std::integral_constant<int, 0>{}, g0);
+    for (int gi = g0; gi < g1; gi += 2) {
+      step(std::integral_constant<int, 0>{}, gi);
+      if (gi + 1 < g1) step(std::integral_constant<int, 1>{}, gi + 1);
+    }
+  }
+
+  __syncthreads();
   {
     double* red = lds + (size_t)w4 * (NFR * NB * 64) + lane;
     for (int pw = 0; pw < NP; ++pw) {

@@ -115,7 +115,13 @@ struct temx_plan {
   std::vector<int> gbatch0;            // first batch of every class-group (+ total)
   DevBuf crow, ycls;
   std::map<int, DevBuf> csplits;       // work cuts per number of pieces
-  Split sp_cproj4, sp_cproj1, sp_ceddy;
+  Split sp_cproj4, sp_cproj1, sp_ceddy, sp_cflux;
+  // one-pass form of the class path: sweep 1 also stores per-class sums of products (csum), the
+  // flux kernel replaces sweep 2 (kernels_cls.hpp)
+  bool onepass = false, op_valid = false;
+  const void* op_ptr[4] = {nullptr, nullptr, nullptr, nullptr};
+  int op_dtype = -1;
+  DevBuf csum, ccnt;
   // shared workspaces
   DevBuf partial;
   // operator-API workspace (any D)
@@ -482,6 +488,7 @@ struct ClassTables {
   std::vector<int> crow;        // [nbatch + 2][4][CLS_MB]
   std::vector<double> xc;       // [4 * (ngroups + 1)] cos(colat) of the class latitude
   std::vector<int> gbatch0;     // [ngroups + 1]
+  std::vector<double> cnt;      // [ngroups][2 sides][4 classes] member counts
   int64_t ncls = 0, ngroups = 0, nbatch = 0;
 };
 
@@ -527,6 +534,7 @@ static bool build_classes(const double* lat, int64_t N, ClassTables& ct) {
   ct.ngroups = (ct.ncls + 3) / 4;
   ct.xc.assign((size_t)(ct.ngroups + 1) * 4, 0.0);
   ct.gbatch0.assign((size_t)ct.ngroups + 1, 0);
+  ct.cnt.assign((size_t)ct.ngroups * 8, 0.0);
   ct.crow.clear();
   const double d2r = M_PI / 180.0;
   for (int64_t gi = 0; gi < ct.ngroups; ++gi) {
@@ -537,6 +545,8 @@ static bool build_classes(const double* lat, int64_t N, ClassTables& ct) {
       bN = std::max(bN, nb(cls[(size_t)ci].n.size()));
       bS = std::max(bS, nb(cls[(size_t)ci].s.size()));
       ct.xc[(size_t)ci] = std::cos((90.0 - cls[(size_t)ci].alat) * d2r);
+      ct.cnt[(size_t)gi * 8 + k] = (double)cls[(size_t)ci].n.size();
+      ct.cnt[(size_t)gi * 8 + 4 + k] = (double)cls[(size_t)ci].s.size();
     }
     ct.gbatch0[(size_t)gi] = (int)(ct.crow.size() / (4 * MB));
     for (int side = 0; side < 2; ++side) {
@@ -568,13 +578,21 @@ static bool build_classes(const double* lat, int64_t N, ClassTables& ct) {
 
 // (first batch, its group) of `nsub` pieces of the batch list: equal batch counts; a cut may fall
 // inside a class-group (the sweeps are linear in the member rows, the kernels project partial sums)
-static int class_cuts(temx_plan* pl, int nsub, const int2** out) {
-  auto it = pl->csplits.find(nsub);
+static int class_cuts(temx_plan* pl, int nsub, const int2** out, bool group_aligned = false) {
+  const int key = group_aligned ? -nsub : nsub;
+  auto it = pl->csplits.find(key);
   if (it == pl->csplits.end()) {
     std::vector<int> cut((size_t)2 * (nsub + 1));
     int g = 0;
     for (int k = 0; k <= nsub; ++k) {
       const int64_t b = pl->cbatches * k / nsub;
+      if (group_aligned) {     // the one-pass sweep stores whole-class sums: cut at the next group boundary
+        while (g < pl->cgroups && pl->gbatch0[(size_t)g] < b) ++g;
+        if (k == nsub) g = (int)pl->cgroups;
+        cut[(size_t)2 * k] = pl->gbatch0[(size_t)g];
+        cut[(size_t)2 * k + 1] = g;
+        continue;
+      }
       while (g + 1 < pl->cgroups && pl->gbatch0[(size_t)g + 1] <= b) ++g;
       cut[(size_t)2 * k] = (int)b;
       cut[(size_t)2 * k + 1] = g;
@@ -582,7 +600,7 @@ static int class_cuts(temx_plan* pl, int nsub, const int2** out) {
     DevBuf b;
     int rc = upload(b, cut.data(), cut.size() * sizeof(int));
     if (rc) return rc;
-    it = pl->csplits.emplace(nsub, b).first;
+    it = pl->csplits.emplace(key, b).first;
   }
   *out = static_cast<const int2*>(it->second.p);
   return TEMX_OK;
@@ -594,6 +612,12 @@ static int class_cuts(temx_plan* pl, int nsub, const int2** out) {
 #ifndef TEMX_CLS_E_PD
 #define TEMX_CLS_E_PD 2
 #endif
+#ifndef TEMX_CLS_OP_WPS
+#define TEMX_CLS_OP_WPS 1
+#endif
+#ifndef TEMX_CLS_OP_PD
+#define TEMX_CLS_OP_PD 3
+#endif
 #ifndef TEMX_CLS_MINCHUNK
 #define TEMX_CLS_MINCHUNK 1
 #endif
@@ -601,27 +625,39 @@ constexpr int CLS_PROJ_E_WPS = TEMX_CLS_E_WPS, CLS_PROJ_E_PD = TEMX_CLS_E_PD;   
 
 template <typename T, int NF>
 static int launch_project_cls_t(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t D, const double* colscale,
-                                int sfield, double* partial, const Split& sp, hipStream_t st) {
+                                int sfield, double* partial, const Split& sp, hipStream_t st, double* csum) {
   const int2* cuts = nullptr;
-  if (int rc = class_cuts(pl, sp.nsplit, &cuts)) return rc;
+  if (int rc = class_cuts(pl, sp.nsplit, &cuts, csum != nullptr)) return rc;
   dim3 grid(sp.grid), block(256);
-#define TEMX_LPC(TBSv, NFWv, WPSv)                                                                  \
-  hipLaunchKernelGGL((project_cls_kernel<T, NF, NFWv, TBSv, WPSv, (NFWv == 1 ? CLS_PROJ_E_PD : 2)>), grid, block, 0, st, fp, D, pl->K, \
+#define TEMX_LPC(TBSv, NFWv, WPSv, OPv)                                                             \
+  hipLaunchKernelGGL((project_cls_kernel<T, NF, NFWv, TBSv, WPSv, (OPv ? TEMX_CLS_OP_PD : (NFWv == 1 ? CLS_PROJ_E_PD : 2)), OPv>), grid, block, 0, st, fp, D, pl->K, \
                      pl->ycls.d(), static_cast<const int4*>(pl->crow.p), cuts, colscale, sfield,    \
-                     partial, sp.nsplit, sp.ndt)
+                     partial, sp.nsplit, sp.ndt, csum)
+  if constexpr (NF == 4) {
+    if (csum != nullptr) {          // one-pass form: quads of d-tiles, all four fields per wave
+      switch (pl->TBS) {
+        case 2: TEMX_LPC(2, 4, TEMX_CLS_OP_WPS, true); break;
+        case 4: TEMX_LPC(4, 4, TEMX_CLS_OP_WPS, true); break;
+        case 7: TEMX_LPC(7, 4, TEMX_CLS_OP_WPS, true); break;
+        default: TEMX_LPC(8, 4, TEMX_CLS_OP_WPS, true); break;
+      }
+      HIPCHK(hipGetLastError());
+      return TEMX_OK;
+    }
+  }
   if (NF == 1 || sp.dpw == 1) {     // one field per wave (NF = 4: small ragged D, one d-tile per workgroup)
     switch (pl->TBS) {
-      case 2: TEMX_LPC(2, 1, CLS_PROJ_E_WPS); break;
-      case 4: TEMX_LPC(4, 1, CLS_PROJ_E_WPS); break;
-      case 7: TEMX_LPC(7, 1, CLS_PROJ_E_WPS); break;
-      default: TEMX_LPC(8, 1, CLS_PROJ_E_WPS); break;
+      case 2: TEMX_LPC(2, 1, CLS_PROJ_E_WPS, false); break;
+      case 4: TEMX_LPC(4, 1, CLS_PROJ_E_WPS, false); break;
+      case 7: TEMX_LPC(7, 1, CLS_PROJ_E_WPS, false); break;
+      default: TEMX_LPC(8, 1, CLS_PROJ_E_WPS, false); break;
     }
   } else {
     switch (pl->TBS) {
-      case 2: TEMX_LPC(2, NF, 2); break;
-      case 4: TEMX_LPC(4, NF, 2); break;
-      case 7: TEMX_LPC(7, NF, 2); break;
-      default: TEMX_LPC(8, NF, 2); break;
+      case 2: TEMX_LPC(2, NF, 2, false); break;
+      case 4: TEMX_LPC(4, NF, 2, false); break;
+      case 7: TEMX_LPC(7, NF, 2, false); break;
+      default: TEMX_LPC(8, NF, 2, false); break;
     }
   }
 #undef TEMX_LPC
@@ -632,9 +668,9 @@ static int launch_project_cls_t(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t 
 template <int NF>
 static int launch_project_cls(temx_plan* pl, const FieldPtrs<NF>& fp, int dtype, int64_t D,
                               const double* colscale, int sfield, double* partial, const Split& sp,
-                              hipStream_t st) {
-  if (dtype == TEMX_F64) return launch_project_cls_t<double, NF>(pl, fp, D, colscale, sfield, partial, sp, st);
-  if (dtype == TEMX_F32) return launch_project_cls_t<float, NF>(pl, fp, D, colscale, sfield, partial, sp, st);
+                              hipStream_t st, double* csum = nullptr) {
+  if (dtype == TEMX_F64) return launch_project_cls_t<double, NF>(pl, fp, D, colscale, sfield, partial, sp, st, csum);
+  if (dtype == TEMX_F32) return launch_project_cls_t<float, NF>(pl, fp, D, colscale, sfield, partial, sp, st, csum);
   return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
 }
 
@@ -674,6 +710,38 @@ static int launch_eddy_cls_t(temx_plan* pl, const FieldPtrs<4>& fp, const double
     case 1: return launch_eddy_cls_d<T, MODE, 1, KIND>(pl, fp, C, partial, sp, eo, st);
     case 2: return launch_eddy_cls_d<T, MODE, 2, KIND>(pl, fp, C, partial, sp, eo, st);
     default: return launch_eddy_cls_d<T, MODE, 4, KIND>(pl, fp, C, partial, sp, eo, st);
+  }
+}
+
+template <int DPW>
+static int launch_flux_cls_d(temx_plan* pl, const double* C, double* partial, const Split& sp, hipStream_t st) {
+  dim3 grid(sp.grid), block(512);
+#define TEMX_LFC(TBSv)                                                                                \
+  do {                                                                                                \
+    auto kern = flux_cls_kernel<TBSv, DPW>;                                                           \
+    const size_t lds = ((size_t)DPW * 4 * 2 * TBSv * 64 + 8 * 2 * TBSv * 16) * sizeof(double);        \
+    static std::atomic<uint64_t> attr_set{0};                                                         \
+    if (int rc_ = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(kern), (int)lds)) \
+      return rc_;                                                                                     \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, pl->D, pl->K, pl->K4, pl->ycls.d(), pl->csum.d(),  \
+                       pl->ccnt.d(), pl->cgroups, C, partial, sp.nsplit, sp.ndt);                     \
+  } while (0)
+  switch (pl->TBS) {
+    case 2: TEMX_LFC(2); break;
+    case 4: TEMX_LFC(4); break;
+    case 7: TEMX_LFC(7); break;
+    default: TEMX_LFC(8); break;
+  }
+#undef TEMX_LFC
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+static int launch_flux_cls(temx_plan* pl, const double* C, double* partial, const Split& sp, hipStream_t st) {
+  switch (sp.dpw) {
+    case 1: return launch_flux_cls_d<1>(pl, C, partial, sp, st);
+    case 2: return launch_flux_cls_d<2>(pl, C, partial, sp, st);
+    default: return launch_flux_cls_d<4>(pl, C, partial, sp, st);
   }
 }
 
@@ -946,6 +1014,8 @@ void temx_plan_destroy(temx_plan* pl) {
   for (DevBuf* b : bufs) b->release();
   pl->crow.release();
   pl->ycls.release();
+  pl->csum.release();
+  pl->ccnt.release();
   pl->gblk.release();
   pl->ypblk.release();
   for (auto& kv : pl->csplits) kv.second.release();
@@ -1071,6 +1141,7 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
     if (!pl->large && !(flags & (TEMX_NO_SYMMETRY | TEMX_NO_CLASSES)) && !(e0 && e0[0] == '1') &&
         !(e1 && e1[0] == '1') && build_classes(lat_deg_host, ncol, ct)) {
       if ((rc = upload(pl->crow, ct.crow.data(), ct.crow.size() * sizeof(int)))) return bail(rc);
+      if ((rc = upload(pl->ccnt, ct.cnt.data(), ct.cnt.size() * 8))) return bail(rc);
       DevBuf xc;
       if ((rc = upload(xc, ct.xc.data(), ct.xc.size() * 8))) return bail(rc);
       rc = pl->ycls.ensure((size_t)(ct.ngroups + 1) * 2 * pl->TBS * 16 * 8);
@@ -1126,6 +1197,8 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
 int temx_plan_is_paired(const temx_plan* pl) { return pl && (pl->sym || pl->cls) ? 1 : 0; }
 
 int temx_plan_sweep_mode(const temx_plan* pl) { return !pl ? -1 : (pl->cls ? 2 : (pl->sym ? 1 : 0)); }
+
+int temx_plan_one_pass(const temx_plan* pl) { return pl && pl->cls && pl->onepass ? 1 : 0; }
 
 int temx_plan_finalize(temx_plan* pl, const double* G_host) {
   if (!pl) return fail(TEMX_EINVAL, "null plan");
@@ -1323,13 +1396,40 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
     const bool quad = pick_dpw(ndt_, 4) == 4;
     const int64_t cunits = std::max<int64_t>(1, pl->cbatches / 4);   // work units of ~4 batches (one cubed-sphere class-group)
     pl->sp_cproj4 = choose_split(D, cunits, (quad ? 2 : CLS_PROJ_E_WPS) * pl->num_cu, quad ? 4 : 1, TEMX_CLS_MINCHUNK);
+    // one-pass form of sweep 1: quads of d-tiles, pieces of >= 8 class-groups (its cuts are group aligned)
+    Split sp_op = choose_split(D, cunits, TEMX_CLS_OP_WPS * pl->num_cu, 4, 8);
     pl->sp_cproj1 = choose_split(D, cunits, CLS_PROJ_E_WPS * pl->num_cu, 4, TEMX_CLS_MINCHUNK);
     pl->sp_ceddy = choose_split(D, cunits / (8 / edpw), pl->num_cu, edpw, TEMX_CLS_MINCHUNK);
     const size_t need3 = (size_t)std::max({pl->sp_cproj4.nsplit * 4, pl->sp_ceddy.nsplit * (8 / edpw) * 3,
                                            pl->sp_cproj1.nsplit}) * pl->K * D * 8;
     if ((rc = pl->partial.ensure(std::max(need3, pl->partial.bytes)))) return rc;
+    // one-pass form: quads of d-tiles, enough class-groups per piece for group-aligned cuts to balance,
+    // and room for the class sums (14 x 512 B per class-group and d-tile)
+    pl->onepass = false;
+    pl->op_valid = false;
+    {
+      const char* e2 = getenv("TEMX_TWO_PASS");
+      const char* e3 = getenv("TEMX_ONE_PASS");   // =1: whenever possible (tests)
+      const bool force = e3 && e3[0] == '1';
+      // a ragged last quad only idles a few waves; below ~16 d-tiles the two-pass sweeps (more waves
+      // per CU) are as fast or faster (measured: ne30x72x2 0.137 vs 0.156 ms, ne30x72x4 0.223 vs 0.203)
+      const bool quad_op = force ? ndt_ >= 4 : (ndt_ >= 16 || (quad && ndt_ >= 8));
+      if (quad_op && !(e2 && e2[0] == '1')) {
+        const size_t need_cs = (size_t)pl->cgroups * ndt_ * 14 * 64 * 8;
+        size_t fr = 0, tot = 0;
+        if (pl->csum.bytes >= need_cs ||
+            (hipMemGetInfo(&fr, &tot) == hipSuccess && need_cs < fr / 2 && pl->csum.ensure(need_cs) == TEMX_OK)) {
+          pl->onepass = true;
+          pl->sp_cproj4 = sp_op;
+          pl->sp_cflux = choose_split(D, std::max<int64_t>(1, pl->cgroups / (8 / edpw)), pl->num_cu, edpw, TEMX_CLS_MINCHUNK);
+          const size_t need4 = (size_t)std::max(pl->sp_cflux.nsplit * 3, sp_op.nsplit * 4) * pl->K * D * 8;
+          if ((rc = pl->partial.ensure(std::max(need4, pl->partial.bytes)))) return rc;
+        }
+      }
+    }
     // work cuts now, not at the first launch: launches must stay legal inside a stream capture
     const int2* cuts_unused = nullptr;
+    if (pl->onepass && (rc = class_cuts(pl, pl->sp_cproj4.nsplit, &cuts_unused, true))) return rc;
     for (int nsub : {pl->sp_cproj4.nsplit, pl->sp_cproj1.nsplit, pl->sp_ceddy.nsplit * (8 / edpw)})
       if ((rc = class_cuts(pl, nsub, &cuts_unused))) return rc;
   }
@@ -1373,7 +1473,13 @@ int temx_tem_stage1(temx_plan* pl, const void* ua, const void* va, const void* t
   time_begin(pl, 0, st, tl);
   const bool sp4 = sym_project(pl, 4);
   const Split& sp = pl->cls ? pl->sp_cproj4 : (sp4 ? pl->sp_sproj4 : pl->sp_proj4);
-  rc = pl->cls ? launch_project_cls<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->partial.d(), sp, st)
+  if (pl->cls && pl->onepass) {   // remember whose class sums csum holds
+    for (int i = 0; i < 4; ++i) pl->op_ptr[i] = fp.p[i];
+    pl->op_dtype = dtype;
+    pl->op_valid = true;
+  }
+  rc = pl->cls ? launch_project_cls<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->partial.d(), sp, st,
+                                       pl->onepass ? pl->csum.d() : nullptr)
        : sp4   ? launch_project_sym<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->partial.d(), sp, st)
                : launch_project<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->partial.d(), sp, st);
   time_end(pl, 0, st, tl);
@@ -1444,10 +1550,16 @@ int temx_tem_stage2(temx_plan* pl, const void* ua, const void* va, const void* t
   if ((rc = launch_solve(pl, B4, 4, pl->D, pl->C4.d(), pl->zb.d(), st))) return rc;
   TimedLaunch tl{};
   time_begin(pl, 1, st, tl);
-  rc = run_eddy<0>(pl, four(ua, va, ta, wap), dtype, pl->C4.d(), pl->partial.d(), nullptr, st);
+  // one-pass class path: the class sums of these very fields are in csum (temx_tem_stage1) -- the
+  // eddy-product sums follow algebraically, the fields are not read again
+  const bool flux = pl->cls && pl->onepass && pl->op_valid && pl->op_dtype == dtype && pl->op_ptr[0] == ua &&
+                    pl->op_ptr[1] == va && pl->op_ptr[2] == ta && pl->op_ptr[3] == wap;
+  rc = flux ? launch_flux_cls(pl, pl->C4.d(), pl->partial.d(), pl->sp_cflux, st)
+            : run_eddy<0>(pl, four(ua, va, ta, wap), dtype, pl->C4.d(), pl->partial.d(), nullptr, st);
   time_end(pl, 1, st, tl);
   if (rc) return rc;
-  return launch_reduce(pl, pl->partial.d(), eddy_slabs(pl), (int64_t)3 * pl->K * pl->D, B3, st);
+  return launch_reduce(pl, pl->partial.d(), flux ? pl->sp_cflux.nsplit : eddy_slabs(pl),
+                       (int64_t)3 * pl->K * pl->D, B3, st);
 }
 
 int temx_tem_stage3(temx_plan* pl, const double* B3, double* results, double* zonal, void* stream) {

@@ -54,6 +54,11 @@ class Plan:
         """0 generic sweeps, 1 mirror-paired sweeps, 2 latitude-class sweeps."""
         return int(self.lib.temx_plan_sweep_mode(self._h))
 
+    @property
+    def one_pass(self):
+        """True when (after ``set_tem``) the class path reads the fields once (see include/temx.h)."""
+        return bool(self.lib.temx_plan_one_pass(self._h))
+
     # ---- lifetime ----
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

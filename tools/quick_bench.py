@@ -26,7 +26,7 @@ def run(ne, nlev, nt, reps=5, dtype=torch.float64):
     p_ms, _ = plan.kernel_timing_read(0); e_ms, _ = plan.kernel_timing_read(1)
     pts = lat.size * nlev * nt
     fl_p, fl_e = pts * 4 * 2 * 51, pts * 7 * 2 * 51
-    print("[mode=%d] " % plan.sweep_mode, end="")
+    print("[mode=%d%s] " % (plan.sweep_mode, "/1pass" if plan.one_pass else ""), end="")
     print("ne%d x %d x %d %s: N=%d pts=%.3g | plan %.2fs | total %.3f ms -> %.3g pts/s (%.1f%% of 7.0e10) | project %.3f ms "
           "(%.1f TF alg, %.2f TB/s) | eddy %.3f ms (%.1f TF alg, %.2f TB/s) | rest %.3f ms | nonfinite=%s" % (
           ne, nlev, nt, str(dtype)[6:], lat.size, pts, tplan, ms, pts / ms * 1e3, pts / ms * 1e3 / 7.0e10 * 100,
