@@ -59,6 +59,7 @@ def cpu_baseline_and_parity(plan_factory, lat, lon, plev, nt_s, device):
     t_cpu = time.perf_counter() - t0
     plan = plan_factory()
     plan.set_tem(len(plev), nt_s, plev * 100)
+    one_pass = plan.one_pass
     res, _ = plan.tem_run(*f)
     bad = plan.status()
     res = res.cpu().numpy()
@@ -74,7 +75,7 @@ def cpu_baseline_and_parity(plan_factory, lat, lon, plev, nt_s, device):
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
     return {"value": pts / t_cpu, "unit": "grid-points/s", "cores": cores, "kind": "port",
             "sample": "ne%d grid (%d cols) x %d lev x %d of the snapshots, oracle/tem_oracle.py "
-                      "factorised numpy restatement, %.1f s" % (0, lat.size, len(plev), nt_s, t_cpu)}, err, bad
+                      "factorised numpy restatement, %.1f s" % (0, lat.size, len(plev), nt_s, t_cpu)}, err, bad, one_pass
 
 
 def main():
@@ -89,6 +90,8 @@ def main():
     ap.add_argument("--cpu-sample-nt", type=int, default=2)
     ap.add_argument("--no-symmetry", action="store_true",
                     help="force the generic sweeps (neither latitude classes nor mirror pairing)")
+    ap.add_argument("--two-pass", action="store_true",
+                    help="latitude-class sweeps in their two-pass form (fields read twice)")
     ap.add_argument("--no-classes", action="store_true",
                     help="do not use the latitude-class sweeps (mirror-paired sweeps on a symmetric grid)")
     ap.add_argument("--no-ncol-extra", action="store_true",
@@ -97,6 +100,8 @@ def main():
     ap.add_argument("--also", default="ne30x72x1",
                     help="comma list of extra (small) workloads timed after the main one, N=1 only")
     args = ap.parse_args()
+    if args.two_pass:
+        os.environ["TEMX_TWO_PASS"] = "1"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -184,6 +189,7 @@ def main():
     eddy_ms, neddy = plan.kernel_timing_read(1)
     plan.kernel_timing(False)
 
+    one_pass_main = plan.one_pass
     ms_per_step = elapsed / args.steps * 1e3
     value = pts_job * args.steps / elapsed
     pts_rank = lat_l.size * nlev * nt_l
@@ -197,19 +203,37 @@ def main():
         "config": {"workload": "ne%d (%d cols) x %d lev x %d snapshots per %s, L=50, 1-degree zonal grid (M=180), "
                                "ten GM16 Table-A1 outputs" % (ne, ncol, nlev, nt, "GPU" if scaling == "weak" else "job"),
                    "shard": args.shard if (world > 1 or use_ncol) else "none", "ncol": int(ncol), "nlev": nlev, "nt": nt,
-                   "sweeps": ("generic", "mirror-paired", "latitude-class")[plan.sweep_mode],
+                   "sweeps": ("generic", "mirror-paired", "latitude-class")[plan.sweep_mode]
+                             + (", one pass" if plan.one_pass else ""),
                    "mirror_paired_sweeps": bool(plan.paired)},
         "plan_build_s": plan_s,
         # dense-operator roofline of SURVEY 8(d): max(64 B / 8 TB/s, 1122 flop / 78.6 TF) per point.  The
         # latitude-class sweeps do the MFMA work per class, not per column, so on grids with repeated
         # latitudes the pipeline can exceed the MFMA side and is bounded by the two compulsory reads.
         "pipeline_frac_of_fp64_roofline": value / world / (PEAK_F64_TFLOPS * 1e12 / FLOPS_PER_PT),
-        "pipeline_frac_of_hbm_roofline": value / world / (PEAK_HBM_GBS * 1e9 / (8 * (8 if args.dtype == "f64" else 4))),
+        # HBM roofline of the path as run: two compulsory reads of the four fields (8 s bytes/point), or
+        # one (4 s) when the one-pass class path is in use
+        "pipeline_frac_of_hbm_roofline": value / world / (PEAK_HBM_GBS * 1e9 / ((4 if plan.one_pass else 8)
+                                                                              * (8 if args.dtype == "f64" else 4))),
+        "hbm_roofline_bytes_per_point": (4 if plan.one_pass else 8) * (8 if args.dtype == "f64" else 4),
         "nonfinite": bool(nonfinite),
     }
     if neddy:
         ach = 7 * 2 * K_HARM * pts_rank / (eddy_ms * 1e-3) / 1e12
-        if plan.sweep_mode == 2:
+        if plan.one_pass and nproj:
+            # one-pass class path: the dominant kernel is sweep 1 (the only read of the fields)
+            gbs_p = 4 * esize * pts_rank / (proj_ms * 1e-3) / 1e9
+            rec["roofline"] = {"kernel": "project_cls_kernel, one-pass form (theta + class sums of the fields and of u v, "
+                                         "u omega, v theta + 4 class projections)",
+                               "bound": "hbm", "achieved": gbs_p, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": gbs_p / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": proj_ms,
+                               "launches": nproj,
+                               "algorithmic": "4 fields x %d B per grid point (the one compulsory read of u, v, T, omega) x "
+                                              "%d points per launch; the kernel also stores 14 class sums per class-group "
+                                              "and d-tile (see traffic)" % (esize, pts_rank)}
+            rec["roofline_flux"] = {"kernel": "flux_cls_kernel (class reconstructions, algebraic eddy-product sums, "
+                                              "3 class projections)", "avg_launch_ms": eddy_ms, "launches": neddy}
+        elif plan.sweep_mode == 2:
             gbs_e = 4 * esize * pts_rank / (eddy_ms * 1e-3) / 1e9
             rec["roofline"] = {"kernel": "eddy_cls_kernel (class reconstructions + eddies + products + class projections)",
                                "bound": "hbm", "achieved": gbs_e, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -235,10 +259,11 @@ def main():
                 j = json.load(open(tr))
                 if (j.get("workload") == args.workload and j.get("dtype") == args.dtype
                         and j.get("sweeps", "mirror-paired") == rec["config"]["sweeps"]):
-                    rec["roofline"]["traffic"] = j.get("eddy_kernel_hbm_bytes_per_launch")
+                    rec["roofline"]["traffic"] = j.get("project_kernel_hbm_bytes_per_launch" if plan.one_pass
+                                                       else "eddy_kernel_hbm_bytes_per_launch")
             except Exception:
                 pass
-    if nproj:
+    if nproj and not rec["config"]["sweeps"].endswith("one pass"):
         gbs = 4 * esize * pts_rank / (proj_ms * 1e-3) / 1e9
         rec["roofline_project"] = {"kernel": "project kernel (theta + 4 projections)", "bound": "hbm",
                                    "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -274,12 +299,15 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         del fields
         torch.cuda.empty_cache()
-        cb, err, bad = cpu_baseline_and_parity(lambda: engine.Plan(lat, lat_zm, K_HARM - 1, device=local_rank),
-                                               lat, lon, plev, args.cpu_sample_nt, local_rank)
+        if one_pass_main:    # the sample has few d-tiles: make it take the code path that was timed
+            os.environ["TEMX_ONE_PASS"] = "1"
+        cb, err, bad, op_s = cpu_baseline_and_parity(
+            lambda: engine.Plan(lat, lat_zm, K_HARM - 1, device=local_rank, symmetry=not args.no_symmetry,
+                                classes=not args.no_classes), lat, lon, plev, args.cpu_sample_nt, local_rank)
         cb["sample"] = cb["sample"].replace("ne0", "ne%d" % ne)
         rec["cpu_baseline"] = cb
         rec["parity_vs_oracle_on_sample"] = {"max_field_normalised_err": err, "tolerance": 1e-10,
-                                            "ok": bool(err <= 1e-10 and not bad)}
+                                            "ok": bool(err <= 1e-10 and not bad), "one_pass": bool(op_s)}
     plan.close()
 
     if world > 1 and not use_ncol and not args.no_ncol_extra:
@@ -323,7 +351,8 @@ def main():
                             % (ne, ncol, nlev, nt),
                 "collectives": "2 RCCL all-reduces per step ([4][K][D] and [3][K][D] fp64 = %d bytes) + the "
                                "K x K Gram matrix once at plan build" % (7 * K_HARM * nlev * nt * 8),
-                "sweeps": ("generic", "mirror-paired", "latitude-class")[p3.sweep_mode], "nonfinite": bool(bad3)}
+                "sweeps": ("generic", "mirror-paired", "latitude-class")[p3.sweep_mode]
+                          + (", one pass" if p3.one_pass else ""), "nonfinite": bool(bad3)}
             p3.close()
         except Exception as e:  # noqa: BLE001 - the metric line must survive a failure of the extra
             rec["ncol_sharded"] = {"error": "%s: %s" % (type(e).__name__, e)}
