@@ -36,6 +36,12 @@ namespace temx {
 #define TEMX_XLOAD(p) (*(p))
 #endif
 
+#ifdef TEMX_NT_CSUM
+#define TEMX_CSTORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define TEMX_CSTORE(p, v) (*(p) = (v))
+#endif
+
 constexpr int CLS_MB = 4;                     // member rows per class and batch
 constexpr int CLS_PADB = 5;                   // batches of padding behind crow (index loads run ahead)
 constexpr int CLS_ROWMASK = 0x0FFFFFFF;
@@ -193,15 +199,15 @@ project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
           double* o = csum + (((int64_t)grp * ndt + dt) * 14) * 64 + lane;
 #pragma unroll
           for (int f = 0; f < 4; ++f) {
-            o[f * 64] = sN[f] * sc[f];
-            o[(7 + f) * 64] = sS[f] * sc[f];
+            TEMX_CSTORE(o + f * 64, sN[f] * sc[f]);
+            TEMX_CSTORE(o + (7 + f) * 64, sS[f] * sc[f]);
           }
-          o[4 * 64] = qN[0];
-          o[5 * 64] = qN[1];
-          o[6 * 64] = qN[2] * sc[2];
-          o[11 * 64] = qS[0];
-          o[12 * 64] = qS[1];
-          o[13 * 64] = qS[2] * sc[2];
+          TEMX_CSTORE(o + 4 * 64, qN[0]);
+          TEMX_CSTORE(o + 5 * 64, qN[1]);
+          TEMX_CSTORE(o + 6 * 64, qN[2] * sc[2]);
+          TEMX_CSTORE(o + 11 * 64, qS[0]);
+          TEMX_CSTORE(o + 12 * 64, qS[1]);
+          TEMX_CSTORE(o + 13 * 64, qS[2] * sc[2]);
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) qN[q] = qS[q] = 0.0;
