@@ -220,3 +220,28 @@ def test_sweep_form_is_chosen_from_the_latitudes(eng):
         assert plan.sweep_mode == expect, (lat.size, want, plan.sweep_mode)
         assert plan.paired == (expect > 0)
         plan.close()
+
+
+@pytest.mark.parametrize("one_pass", [False, True])
+def test_one_pass_class_path_vs_reference_golden(eng, one_pass, monkeypatch):
+    """ne4 x 16 x 4 (D = 64, one quad of d-tiles) computed by the reference itself: the class path in its
+    two-pass and in its one-pass form (forced: the shape is below the 16 d-tiles where it is the default)."""
+    from pytemdiags_amd import _lib
+    if one_pass:
+        monkeypatch.setenv("TEMX_ONE_PASS", "1")
+    g = load("tem_ne4_16x4_f64")
+    plan = eng.Plan(g["lat"], g["lat_zm"], int(g["L"]))
+    nlev, nt = g["ua"].shape[1:]
+    plan.set_tem(nlev, nt, g["plev"] * 100)
+    structured = not any(os.environ.get(k) == "1" for k in ("TEMX_NO_SYM", "TEMX_NO_CLS"))
+    assert plan.one_pass == (one_pass and structured and os.environ.get("TEMX_TWO_PASS") != "1")
+    res, zon = plan.tem_run(dev(g["ua"]), dev(g["va"]), dev(g["ta"]), dev(g["wap"]), want_zonal=True)
+    assert not plan.status()
+    res, zon = res.cpu().numpy(), zon.cpu().numpy()
+    for i, n in enumerate(_lib.RESULT_NAMES):
+        e = fieldnorm_err(res[i], g["res_" + n])
+        assert e <= TOL64, (n, e)
+    for i, n in enumerate(_lib.ZONAL_NAMES):
+        e = fieldnorm_err(zon[i], g["zm_" + n])
+        assert e <= TOL64, (n, e)
+    plan.close()

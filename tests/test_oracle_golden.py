@@ -10,7 +10,7 @@ from conftest import GOLDEN, fieldnorm_err
 from oracle import tem_oracle as orc
 
 TEM_CASES = ["tem_ne4_30x1_f64", "tem_ne4_30x1_f32", "tem_ne4_30x1_desc",
-             "tem_ne4_12x3_L20_dlat3", "tem_ne8_20x2_f64"]
+             "tem_ne4_12x3_L20_dlat3", "tem_ne8_20x2_f64", "tem_ne4_16x4_f64"]
 
 
 def load(name):

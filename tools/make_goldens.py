@@ -135,11 +135,23 @@ def tracer_case(name, ne, nlev, nt, qdtypes=(np.float64, np.float64), dtype=np.f
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    tem_case("tem_ne4_30x1_f64", 4, 30, 1)                                   # BASELINE config 1
-    tem_case("tem_ne4_30x1_f32", 4, 30, 1, dtype=np.float32)
-    tem_case("tem_ne4_30x1_desc", 4, 30, 1, descending=True, keep_native=False)
-    tem_case("tem_ne4_12x3_L20_dlat3", 4, 12, 3, L=20, zm_dlat=3, keep_native=False, seed=5)
-    tem_case("tem_ne8_20x2_f64", 8, 20, 2, keep_native=False, seed=1)
-    operator_case("op_ne4_L30", 4, 30)
-    tracer_case("tracer_ne4_10x2_f64", 4, 10, 2)
-    tracer_case("tracer_ne4_10x2_qf32", 4, 10, 2, qdtypes=(np.float32,))
+    only = set(sys.argv[1:])                 # optional: names of the fixtures to (re)generate
+
+    def want(name):
+        return not only or name in only
+
+    cases = [
+        (tem_case, ("tem_ne4_30x1_f64", 4, 30, 1), {}),                                   # BASELINE config 1
+        (tem_case, ("tem_ne4_30x1_f32", 4, 30, 1), dict(dtype=np.float32)),
+        (tem_case, ("tem_ne4_30x1_desc", 4, 30, 1), dict(descending=True, keep_native=False)),
+        (tem_case, ("tem_ne4_12x3_L20_dlat3", 4, 12, 3), dict(L=20, zm_dlat=3, keep_native=False, seed=5)),
+        (tem_case, ("tem_ne8_20x2_f64", 8, 20, 2), dict(keep_native=False, seed=1)),
+        # D = 64 = one quad of d-tiles: the smallest shape the one-pass class path takes
+        (tem_case, ("tem_ne4_16x4_f64", 4, 16, 4), dict(keep_native=False, seed=7)),
+        (operator_case, ("op_ne4_L30", 4, 30), {}),
+        (tracer_case, ("tracer_ne4_10x2_f64", 4, 10, 2), {}),
+        (tracer_case, ("tracer_ne4_10x2_qf32", 4, 10, 2), dict(qdtypes=(np.float32,))),
+    ]
+    for fn, a, kw in cases:
+        if want(a[0]):
+            fn(*a, **kw)
