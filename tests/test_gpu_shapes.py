@@ -447,3 +447,30 @@ def test_one_pass_on_uneven_classes(force_one_pass):
         e = fieldnorm_err(res[i].cpu().numpy(), getattr(ref, n)())
         assert e <= 1e-10, (n, e)
     plan.close()
+
+
+def test_one_pass_equals_two_pass_at_baseline_grid_size(monkeypatch):
+    """ne30 (48 602 columns) x 72 x 4 (18 d-tiles: one-pass by default): the one-pass and the two-pass
+    form of the class path are the same computation up to rounding -- no CPU reference needed."""
+    from pytemdiags_amd import _lib, engine, synth
+    lat, lon = synth.cubed_sphere_gll(30)
+    plev = synth.pressure_levels(72)
+    lat_zm = (np.arange(-90, 91, 1.0)[1:] + np.arange(-90, 91, 1.0)[:-1]) / 2
+    f = engine.synth_fields(0, lat, lon, plev, 4)
+    outs, forms = [], []
+    expected = _one_pass_expected()
+    for two in (False, True):
+        if two:
+            monkeypatch.setenv("TEMX_TWO_PASS", "1")
+        plan = engine.Plan(lat, lat_zm, 50)
+        plan.set_tem(72, 4, plev * 100)
+        forms.append(plan.one_pass)
+        res, zon = plan.tem_run(*f, want_zonal=True)
+        assert not plan.status()
+        outs.append((res.cpu().numpy(), zon.cpu().numpy()))
+        plan.close()
+    assert forms[1] is False
+    assert forms[0] == expected
+    for a, b, names in ((outs[0][0], outs[1][0], _lib.RESULT_NAMES), (outs[0][1], outs[1][1], _lib.ZONAL_NAMES)):
+        for i, n in enumerate(names):
+            assert fieldnorm_err(a[i], b[i]) <= 1e-11, (n, fieldnorm_err(a[i], b[i]))
