@@ -281,6 +281,24 @@ reduce_partials_kernel(const double* __restrict__ partial, int nsplit, int64_t n
   }
 }
 
+// Many entries, few slabs (nsplit <= 16): one thread per entry, slabs summed in ascending order --
+// the same association as the kernel above (each of its 16 split lanes then holds at most one slab),
+// so both give identical bits.
+__global__ void __launch_bounds__(256)
+reduce_partials_flat_kernel(const double* __restrict__ partial, int nsplit, int64_t n,
+                            double* __restrict__ B, int* __restrict__ flag) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  double v[16];
+#pragma unroll
+  for (int sp = 0; sp < 16; ++sp) v[sp] = partial[(int64_t)(sp < nsplit ? sp : 0) * n + idx];
+  double t = 0.0;
+#pragma unroll
+  for (int sp = 0; sp < 16; ++sp) t += sp < nsplit ? v[sp] : 0.0;
+  B[idx] = t;
+  if (!(fabs(t) <= 1.79769313486231570815e308)) atomicOr(flag, 1);
+}
+
 // ------------------------------------------------------------------------------------------------
 // solve: C = Ginv . B (harmonic coefficients, pinv(Y0) A = G^-1 Y0^T A, replaces the lstsq of
 // sph_zonal_mean.py:389) and Xb = Y0p . C (the outer matmul with Y = Y0p of :251).

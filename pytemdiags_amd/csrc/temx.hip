@@ -297,6 +297,12 @@ static int launch_project(temx_plan* pl, const FieldPtrs<NF>& fp, int dtype, int
 
 static int launch_reduce(temx_plan* pl, const double* partial, int nsplit, int64_t n, double* B,
                          hipStream_t st) {
+  if (nsplit <= 16 && n >= 32768) {   // many entries, few slabs: one thread per entry (same bits)
+    hipLaunchKernelGGL(reduce_partials_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial,
+                       nsplit, n, B, static_cast<int*>(pl->flag.p));
+    HIPCHK(hipGetLastError());
+    return TEMX_OK;
+  }
   const int64_t blocks = (n + 15) / 16;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)blocks), dim3(256), 0, st, partial, nsplit, n, B,
                      static_cast<int*>(pl->flag.p));
