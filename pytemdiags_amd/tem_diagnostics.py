@@ -361,12 +361,7 @@ class TEMDiagnostics:
         prefix = "{}_".format(prefix) if prefix is not None else ""
         filename = "{}TEM_{}_{}_L{}.nc".format(prefix, self.ZM.grid_name, self.ZM.grid_out_name, self.L)
         self._out_file = "{}/{}".format(loc, filename)
-        try:
-            import xarray as xr
-        except ImportError as e:
-            raise RuntimeError("to_netcdf() needs xarray and a NetCDF back end, which are not installed; "
-                               "use results() and write the arrays yourself") from e
-        out = {n: self._as_xr(getattr(self, n)()) for n in _lib.RESULT_NAMES}
+        names = {}
         if include_attrs:   # (sic) key 'wawpp' as in tem_diagnostics.py:1011
             names = {"ub": "ub", "up": "up", "vb": "vb", "vp": "vp", "thetab": "thetab", "thetap": "thetap",
                      "wapb": "wapb", "wawpp": "wapp", "upvp": "upvp", "upvpb": "upvpb", "upwapp": "upwapp",
@@ -374,9 +369,32 @@ class TEMDiagnostics:
                      "dthetab_dp": "dthetab_dp", "ubcoslat": "ubcoslat", "dubcoslat_dlat": "dubcoslat_dlat",
                      "psi": "psi", "psicoslat": "psicoslat", "dpsicoslat_dlat": "dpsicoslat_dlat",
                      "dpsi_dp": "dpsi_dp", "int_vbdp": "int_vbdp"}
-            out = dict({k: self._as_xr(getattr(self, v)) for k, v in names.items()}, **out)
-        xr.Dataset(out).to_netcdf(self._out_file)
+        items = dict({k: getattr(self, v) for k, v in names.items()},
+                     **{n: getattr(self, n)() for n in _lib.RESULT_NAMES})
+        self._write_nc(self._out_file, items)
         return self._out_file
+
+    def _write_nc(self, path, items):
+        """xarray when importable (like the reference); otherwise NetCDF-3 through scipy (ncio.py)."""
+        try:
+            import xarray as xr
+        except ImportError:
+            xr = None
+        if xr is not None:   # pragma: no cover - xarray is absent from this image
+            xr.Dataset({k: self._as_xr(v) for k, v in items.items()}).to_netcdf(path)
+            return
+        from . import ncio
+        variables = {}
+        for k, v in items.items():
+            arr = ncio._np(v)
+            native = arr.shape[0] == self.NCOL and arr.shape[0] != len(self.lat)
+            dims = v.dims if containers.is_labeled(v) else (("ncol" if native else "lat"), self.plevname, self.timename)
+            variables[k] = (tuple(dims), arr, getattr(v, "attrs", None))
+        coords = {"lat": np.asarray(self.lat, dtype=np.float64), self.plevname: np.asarray(self.plev, dtype=np.float64)}
+        t = np.asarray(self.time)
+        if t.dtype.kind in "fiu":
+            coords[self.timename] = t.astype(np.float64)
+        ncio.write_dataset(path, variables, coords)
 
     def _as_xr(self, x):
         import xarray as xr
@@ -394,18 +412,13 @@ class TEMDiagnostics:
         prefix = "{}_".format(prefix) if prefix is not None else ""
         names = [n if n is not None else "q{}".format(i) for i, n in enumerate(self._tracer_names)]
         idx = range(self.ntrac) if qi is None else [qi]
-        try:
-            import xarray as xr
-        except ImportError as e:
-            raise RuntimeError("q_to_netcdf() needs xarray and a NetCDF back end, which are not installed") from e
         for i in idx:
-            out = {n: self._as_xr(getattr(self, n)(i)) for n in _lib.TRACER_RESULT_NAMES}
+            items = {n: getattr(self, n)(i) for n in _lib.TRACER_RESULT_NAMES}
             if include_attrs:   # (sic) key 'dqp_dp' as in tem_diagnostics.py:1081
-                attrs = {"qpvp": self.qpvp[i], "qpwapp": self.qpwapp[i], "qpvpb": self.qpvpb[i],
-                         "qpwappb": self.qpwappb[i], "dqp_dp": self.dqb_dp[i], "qbcoslat": self.qbcoslat[i],
-                         "dqbcoslat_dlat": self.dqbcoslat_dlat[i]}
-                out = dict({k: self._as_xr(v) for k, v in attrs.items()}, **out)
+                items = dict({"qpvp": self.qpvp[i], "qpwapp": self.qpwapp[i], "qpvpb": self.qpvpb[i],
+                              "qpwappb": self.qpwappb[i], "dqp_dp": self.dqb_dp[i], "qbcoslat": self.qbcoslat[i],
+                              "dqbcoslat_dlat": self.dqbcoslat_dlat[i]}, **items)
             self._q_out_file[i] = "{}/{}TEM_{}_{}_L{}_TRACER-{}.nc".format(
                 loc, prefix, self.ZM.grid_name, self.ZM.grid_out_name, self.L, names[i])
-            xr.Dataset(out).to_netcdf(self._q_out_file[i])
+            self._write_nc(self._q_out_file[i], items)
         return self._q_out_file

@@ -213,3 +213,32 @@ def test_latlon_grid_zonal_mean_is_the_longitude_average():
     zmn = ZM.sph_zonal_mean_native(data["F"]).values.reshape(nlat, nlon, nlev)
     for k in range(nlev):
         assert np.max(np.abs(zmn[:, :, k] - prof(s, k)[:, None])) < 1e-11, k
+
+
+def test_to_netcdf_round_trip(tmp_path):
+    """to_netcdf / q_to_netcdf (tem_diagnostics.py:995-1103): file naming, variable set (incl. the
+    reference's 'wawpp' and 'dqp_dp' keys), dims and values; NetCDF-3 through scipy when xarray is absent."""
+    from pytemdiags_amd import TEMDiagnostics, LabeledArray, ncio
+    g = load("tracer_ne4_10x2_f64")
+    q = [LabeledArray(g["q%d" % i], ("ncol", "plev", "time"), {"plev": g["plev"], "time": g["time"]},
+                      name="Q%d" % i) for i in range(int(g["ntrac"]))]
+    tem = TEMDiagnostics(labeled(g, "ua"), labeled(g, "va"), labeled(g, "ta"), labeled(g, "wap"),
+                         LabeledArray(g["lat"], ("ncol",)), q=q, debug_level=0)
+    path = tem.to_netcdf(loc=str(tmp_path), prefix="run1", include_attrs=True)
+    assert path == "%s/run1_TEM_ncol866_1.0deg_L50.nc" % tmp_path and tem.out_file == path
+    ds = ncio.read_dataset(path)
+    want = set(RESULTS) | (set(ZONAL) | set(NATIVE) | {"wawpp"}) - {"wapp"}
+    assert want <= set(ds) and {"lat", "plev", "time"} <= set(ds)
+    for n in RESULTS:
+        dims, v = ds[n]
+        assert dims == ("lat", "plev", "time") and v.dtype == g["res_" + n].dtype
+        assert fieldnorm_err(v, g["res_" + n]) <= 1e-10, n
+    assert ds["wawpp"][0] == ("ncol", "plev", "time") and np.array_equal(ds["wawpp"][1], vals(tem.wapp))
+    np.testing.assert_array_equal(ds["lat"][1], tem.lat)
+    np.testing.assert_allclose(ds["plev"][1], np.sort(g["plev"]))
+    files = tem.q_to_netcdf(loc=str(tmp_path), include_attrs=True)
+    assert files[1].endswith("TEM_ncol866_1.0deg_L50_TRACER-Q1.nc")
+    dq = ncio.read_dataset(files[1])
+    assert {"etfy", "etfz", "etdiv", "qtendetfd", "qtendvtem", "qtendwtem", "dqp_dp", "qpvp"} <= set(dq)
+    assert fieldnorm_err(dq["etdiv"][1], g["q1_res_etdiv"]) <= 1e-10
+    assert dq["qpvp"][0] == ("ncol", "plev", "time")
