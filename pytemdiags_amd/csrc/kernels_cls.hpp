@@ -21,8 +21,17 @@
 //   ycls[group][2*TBS][16]  4x4 blocks at the class latitudes, layout of kernels_sym.hpp's ysym.
 //   csplit[nsub+1]     (first batch, its group) of every piece of work; equal batch counts, cuts may
 //                      fall inside a group (both sweeps are linear in the member rows).
-// No workgroup barriers: each wave stages its own Y blocks (wave-private LDS) and walks its own
-// flat batch list with the X loads one batch ahead and the row indices two.
+// No workgroup barriers in the sweeps' main loops: each wave stages its own Y blocks (wave-private
+// LDS) and walks its own flat batch list with the X loads PD - 1 batches ahead and the row indices one
+// batch further.
+//
+// One-pass form (project_cls_kernel<.., OP = true> + flux_cls_kernel): inside a class side xbar is a
+// constant, so   sum (u - ub)(v - vb) = S_uv - vb S_u - ub S_v + n ub vb.   Sweep 1 also accumulates
+// S_uv, S_uw, S_vT per class and side and stores, per (class-group, d-tile),
+//   csum[group][dt][14][64]   rows 0-6: S_u S_v S_theta S_w S_uv S_uw S_vtheta of the northern members,
+//                             rows 7-13: the same of the southern ones (lane = 16 class + column)
+// and flux_cls_kernel turns them into the projected eddy-product sums after the solve: the fields
+// are read once.  Its work cuts are aligned to class-groups (a stored sum must be complete).
 #pragma once
 #include "kernels_sym.hpp"
 
