@@ -374,12 +374,15 @@ def force_one_pass(monkeypatch):
         monkeypatch.setenv("TEMX_ONE_PASS", "1")
 
 
-@pytest.mark.parametrize("ne,nlev,nt,dtype", [
-    (16, 16, 8, np.float64),     # D = 128: two exact quads of d-tiles
-    (8, 40, 5, np.float64),      # D = 200: 13 d-tiles, ragged last quad and ragged last tile
-    (12, 30, 6, np.float32),     # fp32 inputs
+@pytest.mark.parametrize("ne,nlev,nt,dtype,L", [
+    (16, 16, 8, np.float64, 50),     # D = 128: two exact quads of d-tiles
+    (8, 40, 5, np.float64, 50),      # D = 200: 13 d-tiles, ragged last quad and ragged last tile
+    (12, 30, 6, np.float32, 50),     # fp32 inputs
+    (8, 16, 5, np.float64, 12),      # 2 blocks of even / odd harmonics (TBS = 2)
+    (8, 16, 5, np.float64, 30),      # TBS = 4
+    (8, 16, 5, np.float64, 61),      # TBS = 8
 ])
-def test_one_pass_class_path_vs_oracle(ne, nlev, nt, dtype, force_one_pass):
+def test_one_pass_class_path_vs_oracle(ne, nlev, nt, dtype, L, force_one_pass):
     """One-pass form of the class path (kernels_cls.hpp): sweep 1 stores per-class sums of u v,
     u omega, v theta; the eddy-product sums follow algebraically, the fields are read once."""
     from oracle import tem_oracle as orc
@@ -387,8 +390,8 @@ def test_one_pass_class_path_vs_oracle(ne, nlev, nt, dtype, force_one_pass):
     lat, lon = synth.cubed_sphere_gll(ne)
     plev = synth.pressure_levels(nlev)
     f = synth.analytic_fields(lat, lon, plev, nt, seed=ne, dtype=dtype)
-    ref = orc.TEMOracle(*f, lat, plev, L=50, mode="factorised")
-    plan = engine.Plan(lat, ref.lat, 50)
+    ref = orc.TEMOracle(*f, lat, plev, L=L, mode="factorised")
+    plan = engine.Plan(lat, ref.lat, L)
     plan.set_tem(nlev, nt, plev * 100)
     assert plan.one_pass == _one_pass_expected()
     d = [torch.as_tensor(x, device="cuda:0") for x in f]
