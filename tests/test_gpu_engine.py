@@ -229,6 +229,8 @@ def test_one_pass_class_path_vs_reference_golden(eng, one_pass, monkeypatch):
     from pytemdiags_amd import _lib
     if one_pass:
         monkeypatch.setenv("TEMX_ONE_PASS", "1")
+    else:
+        monkeypatch.delenv("TEMX_ONE_PASS", raising=False)
     g = load("tem_ne4_16x4_f64")
     plan = eng.Plan(g["lat"], g["lat_zm"], int(g["L"]))
     nlev, nt = g["ua"].shape[1:]
