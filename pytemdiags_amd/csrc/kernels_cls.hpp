@@ -28,8 +28,8 @@
 // One-pass form (project_cls_kernel<.., OP = true> + flux_cls_kernel): inside a class side xbar is a
 // constant, so   sum (u - ub)(v - vb) = S_uv - vb S_u - ub S_v + n ub vb.   Sweep 1 also accumulates
 // S_uv, S_uw, S_vT per class and side and stores, per (class-group, d-tile),
-//   csum[group][dt][14][64]   rows 0-6: S_u S_v S_theta S_w S_uv S_uw S_vtheta of the northern members,
-//                             rows 7-13: the same of the southern ones (lane = 16 class + column)
+//   csum[group][dt][7][64][2] sums S_u S_v S_theta S_w S_uv S_uw S_vtheta, per lane (= 16 class + column)
+//                             the {northern, southern} pair: 7 x 16-byte stores / loads per lane
 // and flux_cls_kernel turns them into the projected eddy-product sums after the solve: the fields
 // are read once.  Its work cuts are aligned to class-groups (a stored sum must be complete).
 #pragma once
@@ -205,18 +205,13 @@ project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
         if (lane + 64 * j < YE) yst[lane + 64 * j] = ys[j];
       if constexpr (OP) {                     // 7 sums per side of this (group, d-tile), theta-scaled
         if (dvalid) {
-          double* o = csum + (((int64_t)grp * ndt + dt) * 14) * 64 + lane;
+          // row s of the record = {northern, southern} value of sum s per lane: 7 stores of 16 B
+          double2* o = reinterpret_cast<double2*>(csum + (((int64_t)grp * ndt + dt) * 14) * 64) + lane;
 #pragma unroll
-          for (int f = 0; f < 4; ++f) {
-            TEMX_CSTORE(o + f * 64, sN[f] * sc[f]);
-            TEMX_CSTORE(o + (7 + f) * 64, sS[f] * sc[f]);
-          }
-          TEMX_CSTORE(o + 4 * 64, qN[0]);
-          TEMX_CSTORE(o + 5 * 64, qN[1]);
-          TEMX_CSTORE(o + 6 * 64, qN[2] * sc[2]);
-          TEMX_CSTORE(o + 11 * 64, qS[0]);
-          TEMX_CSTORE(o + 12 * 64, qS[1]);
-          TEMX_CSTORE(o + 13 * 64, qS[2] * sc[2]);
+          for (int f = 0; f < 4; ++f) o[f * 64] = make_double2(sN[f] * sc[f], sS[f] * sc[f]);
+          o[4 * 64] = make_double2(qN[0], qS[0]);
+          o[5 * 64] = make_double2(qN[1], qS[1]);
+          o[6 * 64] = make_double2(qN[2] * sc[2], qS[2] * sc[2]);
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) qN[q] = qS[q] = 0.0;
@@ -577,13 +572,17 @@ flux_cls_kernel(int64_t D, int K, int K4, const double* __restrict__ ycls, const
   double sv[2][14], cn[2][2], ys[2][YJ];
   auto load = [&](auto pc, int gi) __attribute__((always_inline)) {
     constexpr int P = decltype(pc)::value;
-    const double* base = csum + (((int64_t)gi * ndt + (active ? dt : 0)) * 14) * 64 + lane;
+    const double2* base = reinterpret_cast<const double2*>(csum + (((int64_t)gi * ndt + (active ? dt : 0)) * 14) * 64) + lane;
 #pragma unroll
     for (int j = 0; j < YJ; ++j) ys[P][j] = (ycls + (int64_t)gi * YE)[(lane + 64 * j) < YE ? (lane + 64 * j) : 0];
     cn[P][0] = ccnt[(int64_t)gi * 8 + g];
     cn[P][1] = ccnt[(int64_t)gi * 8 + 4 + g];
 #pragma unroll
-    for (int s_ = 0; s_ < 14; ++s_) sv[P][s_] = base[s_ * 64];
+    for (int s_ = 0; s_ < 7; ++s_) {
+      const double2 v2 = base[s_ * 64];
+      sv[P][s_] = v2.x;           // northern members
+      sv[P][7 + s_] = v2.y;       // southern members
+    }
   };
   auto step = [&](auto pc, int gi) __attribute__((always_inline)) {
     constexpr int P = decltype(pc)::value;
