@@ -162,3 +162,20 @@ def test_c_abi_header_is_plain_c_and_links(tmp_path):
     import re
     declared = set(re.findall(r"\b(temx_[a-z0-9_]+)\s*\(", hdr))
     assert declared == {n for n, _, _ in _lib.SIGNATURES}
+
+
+def test_ncio_round_trip(tmp_path):
+    """NetCDF-3 writer behind to_netcdf when xarray is absent: dims, dtypes, coordinates, attributes."""
+    from pytemdiags_amd import ncio, LabeledArray
+    x = np.arange(24.0).reshape(2, 3, 4)
+    y = LabeledArray(np.float32([1.5, 2.5]), ("lat",), name="y", attrs={"units": "K"})
+    path = ncio.write_dataset(str(tmp_path / "a.nc"), {"x": (("lat", "plev", "time"), x, {"long_name": "test"}),
+                                                       "y": (("lat",), y, y.attrs)},
+                              {"lat": [-1.0, 1.0], "plev": [1, 2, 3.0]}, attrs={"title": "t"})
+    ds = ncio.read_dataset(path)
+    assert ds["x"][0] == ("lat", "plev", "time") and ds["x"][1].dtype == np.float64 and np.array_equal(ds["x"][1], x)
+    assert ds["y"][1].dtype == np.float32 and np.array_equal(ds["y"][1], [1.5, 2.5])
+    assert np.array_equal(ds["lat"][1], [-1.0, 1.0]) and np.array_equal(ds["plev"][1], [1.0, 2.0, 3.0])
+    assert "time" not in ds                                 # no coordinate given for it
+    with pytest.raises(ValueError):
+        ncio.write_dataset(str(tmp_path / "b.nc"), {"x": (("lat", "plev"), x)})
