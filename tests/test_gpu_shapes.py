@@ -418,6 +418,14 @@ def test_one_pass_class_path_vs_oracle(ne, nlev, nt, dtype, L, force_one_pass):
     ed = plan.tem_eddy(*d)
     for n in ("up", "vptp"):
         assert fieldnorm_err(ed[n].cpu().numpy(), getattr(ref, n)) <= tol, n
+    if L == 50 and dtype == np.float64:
+        q = synth.analytic_tracer(lat, lon, plev, nt, which=1)
+        refq = orc.TEMOracle(*f, lat, plev, L=L, mode="factorised", q=[q])
+        tres, _ = plan.tracer_run(torch.as_tensor(q, device="cuda:0"), d[1], d[3])
+        for i, n in enumerate(_lib.TRACER_RESULT_NAMES):
+            e = fieldnorm_err(tres[i].cpu().numpy(), getattr(refq, n)(0))
+            assert e <= 1e-10, (n, e)
+    assert not plan.status()
     plan.close()
 
 
