@@ -306,19 +306,14 @@ reduce_partials_flat_kernel(const double* __restrict__ partial, int nsplit, int6
 // K x 16 coefficients (cheap) so that small problems still fill the chip.  C is stored with
 // K4 = 4*TB rows (rows >= K zero) by slice 0.
 // ------------------------------------------------------------------------------------------------
-// STAGE = true (K <= 64): Ginv and this block's Y0p rows are staged in LDS together with the B tile,
-// so the kernel has a single global round trip before its arithmetic (it is latency, not
-// throughput, that matters here: the whole solve is a few hundred KB).
-template <bool STAGE>
+// This scalar version serves K > 64 (64 < K <= 512); K <= 64 uses solve_mfma_kernel below.
 __global__ void __launch_bounds__(1024)
 solve_kernel(const double* __restrict__ B, int K, int K4, int M, int64_t D,
              const double* __restrict__ Ginv, const double* __restrict__ Y0p,
              double* __restrict__ C, double* __restrict__ Xb) {
-  extern __shared__ double slds[];          // sb[K4][17], scf[K4][17], (STAGE) sg[K][K], sy[mper][K]
+  extern __shared__ double slds[];          // sb[K4][17], scf[K4][17]
   double* sb = slds;
   double* scf = slds + (size_t)K4 * 17;
-  double* sg = scf + (size_t)K4 * 17;
-  double* sy = sg + (STAGE ? K * K : 0);
   const int f = blockIdx.y;
   const int64_t d0 = (int64_t)blockIdx.x * 16;
   const int tid = threadIdx.x;
@@ -330,18 +325,13 @@ solve_kernel(const double* __restrict__ B, int K, int K4, int M, int64_t D,
     const int64_t d = d0 + dd;
     sb[k * 17 + dd] = d < D ? B[((int64_t)f * K + k) * D + d] : 0.0;
   }
-  if (STAGE) {
-    for (int idx = tid; idx < K * K; idx += 1024) sg[idx] = Ginv[idx];
-    if (Xb != nullptr)
-      for (int idx = tid; idx < (m1 - m0) * K; idx += 1024) sy[idx] = Y0p[(int64_t)m0 * K + idx];
-  }
   __syncthreads();
   for (int idx = tid; idx < K4 * 16; idx += 1024) {
     const int k = idx >> 4, dd = idx & 15;
     const int64_t d = d0 + dd;
     double v = 0.0;
     if (k < K) {
-      const double* gr = STAGE ? sg + k * K : Ginv + (int64_t)k * K;
+      const double* gr = Ginv + (int64_t)k * K;
       double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;      // four chains: the dot is latency bound
       int kk = 0;
       for (; kk + 4 <= K; kk += 4) {
@@ -362,7 +352,7 @@ solve_kernel(const double* __restrict__ B, int K, int K4, int M, int64_t D,
       const int m = m0 + (idx >> 4), dd = idx & 15;
       const int64_t d = d0 + dd;
       if (d >= D) continue;
-      const double* yr = STAGE ? sy + (m - m0) * K : Y0p + (int64_t)m * K;
+      const double* yr = Y0p + (int64_t)m * K;
       double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
       int kk = 0;
       for (; kk + 4 <= K; kk += 4) {

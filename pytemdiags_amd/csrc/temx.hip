@@ -101,7 +101,7 @@ struct temx_plan {
   DevBuf p, pg, lg, coslat, fcor, colscale;
   DevBuf B4, B3, C4, zb;
   DevBuf Bq, Bq2, Ct, tz;          // tracer workspace: sums, coefficients (q, v, w), zonal means
-  Split sp_proj1, sp_eddy_t;
+  Split sp_proj1;
   // mirror-paired path (equatorially symmetric grids), see kernels_sym.hpp
   bool sym = false;
   int TBS = 0;
@@ -341,8 +341,8 @@ static int launch_solve(temx_plan* pl, const double* B, int NF, int64_t D, doubl
   {
     const size_t slds = (size_t)2 * pl->K4 * 17 * sizeof(double);
     static std::atomic<uint64_t> attr{0};
-    if (int rc = lds_attr_once(attr, pl->device, reinterpret_cast<const void*>(solve_kernel<false>), 160 * 1024)) return rc;
-    hipLaunchKernelGGL(solve_kernel<false>, grid, dim3(1024), slds, st, B, pl->K, pl->K4, pl->M, D, pl->Ginv.d(),
+    if (int rc = lds_attr_once(attr, pl->device, reinterpret_cast<const void*>(solve_kernel), 160 * 1024)) return rc;
+    hipLaunchKernelGGL(solve_kernel, grid, dim3(1024), slds, st, B, pl->K, pl->K4, pl->M, D, pl->Ginv.d(),
                        pl->Y0p.d(), C, Xb);
   }
   HIPCHK(hipGetLastError());
