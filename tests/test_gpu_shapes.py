@@ -485,3 +485,54 @@ def test_one_pass_equals_two_pass_at_baseline_grid_size(monkeypatch):
     for a, b, names in ((outs[0][0], outs[1][0], _lib.RESULT_NAMES), (outs[0][1], outs[1][1], _lib.ZONAL_NAMES)):
         for i, n in enumerate(names):
             assert fieldnorm_err(a[i], b[i]) <= 1e-11, (n, fieldnorm_err(a[i], b[i]))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_random_grids_and_shapes(seed, monkeypatch):
+    """Randomised grids (class sizes 1..20, some classes on one hemisphere, optional structure-free
+    columns), random ncol / nlev / nt / L / dtype and sweep form, whole pipeline vs the oracle."""
+    from oracle import tem_oracle as orc
+    from pytemdiags_amd import _lib, engine, synth
+    rng = np.random.default_rng(1000 + seed)
+    nuniq = int(rng.integers(40, 400))
+    maxm = int(rng.choice([1, 2, 5, 20]))
+    lats = []
+    for a in rng.uniform(0.2, 89.8, nuniq):
+        nn, ns = rng.integers(0, maxm + 1, 2)
+        if nn + ns == 0:
+            nn = 1
+        lats += [a] * int(nn) + [-a] * int(ns)
+    if rng.random() < 0.5:
+        lats += [0.0] * int(rng.integers(1, 6))
+    if rng.random() < 0.5:
+        lats += [90.0, -90.0]
+    if rng.random() < 0.3:
+        lats += list(rng.uniform(-89, 89, int(rng.integers(1, 50))))     # columns without partners
+    lat = np.array(lats)
+    rng.shuffle(lat)
+    lon = rng.uniform(0, 360, lat.size)
+    nlev = int(rng.integers(2, 24))
+    nt = int(rng.integers(1, 9))
+    L = int(rng.integers(3, min(63, nuniq // 2)))
+    dtype = np.float32 if rng.random() < 0.25 else np.float64
+    if rng.random() < 0.5:
+        monkeypatch.setenv("TEMX_ONE_PASS", "1")
+    plev = synth.pressure_levels(nlev)
+    f = synth.analytic_fields(lat, lon, plev, nt, seed=seed, dtype=dtype)
+    ref = orc.TEMOracle(*f, lat, plev, L=L, mode="factorised")
+    plan = engine.Plan(lat, ref.lat, L)
+    plan.set_tem(nlev, nt, plev * 100)
+    res, zon = plan.tem_run(*[torch.as_tensor(x, device="cuda:0") for x in f], want_zonal=True)
+    assert not plan.status()
+    # the oracle and the engine both solve the K x K normal equations; give the tolerance the room
+    # the conditioning of this random grid asks for
+    cond = np.linalg.cond(ref.ZM.Y0.T @ ref.ZM.Y0)
+    tol = (1e-10 if dtype == np.float64 else 2e-5) * max(1.0, cond / 1e4)
+    info = (seed, lat.size, nlev, nt, L, dtype.__name__, plan.sweep_mode, plan.one_pass, "cond %.1e" % cond)
+    for i, n in enumerate(_lib.RESULT_NAMES):
+        e = fieldnorm_err(res[i].cpu().numpy(), getattr(ref, n)())
+        assert e <= tol, (n, e) + info
+    for i, n in enumerate(_lib.ZONAL_NAMES):
+        e = fieldnorm_err(zon[i].cpu().numpy(), getattr(ref, n))
+        assert e <= tol, (n, e) + info
+    plan.close()
