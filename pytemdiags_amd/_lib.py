@@ -84,6 +84,12 @@ def load():
         raise RuntimeError(
             "pytemdiags_amd: HIP extension %s is missing. Build it with `make -C pytemdiags_amd/csrc` "
             "or `python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm ships its own HIP runtime.  Two runtimes in one process do not both see the GPU, so
+    # let torch load first: libtemx.so's libamdhip64 dependency then binds to the runtime already mapped.
+    try:
+        import torch  # noqa: F401
+    except ImportError:      # plain-C / ctypes-only consumers use the system runtime
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SIGNATURES:
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
