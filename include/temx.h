@@ -122,8 +122,9 @@ int temx_plan_sweep_mode(const temx_plan* plan);
 /* 1 when (after temx_plan_set_tem) the latitude-class path runs in its one-pass form: sweep 1 also
  * stores per-class sums of u v, u omega, v theta, and the eddy-product sums of a class follow
  * algebraically from them (the zonal mean is constant inside a class side), so temx_tem_stage2 does
- * not read the fields again.  Needs quads of d-tiles (nlev*nt not tiny) and workspace of 14 x 512 B
- * per class-group and d-tile; TEMX_TWO_PASS=1 in the environment disables. */
+ * not read the fields again.  Used from nlev*nt >= 49 and ncol*nlev*nt >= 1.2e7 up (below that the
+ * two-pass sweeps are as fast); needs workspace of 14 x 512 B per class-group and d-tile;
+ * TEMX_TWO_PASS=1 in the environment disables, TEMX_ONE_PASS=1 lifts the size threshold. */
 int temx_plan_one_pass(const temx_plan* plan);
 
 int temx_get_matrix(temx_plan* plan, int which, double* dst, void* stream);

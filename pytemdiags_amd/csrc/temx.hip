@@ -1417,9 +1417,11 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
       const char* e2 = getenv("TEMX_TWO_PASS");
       const char* e3 = getenv("TEMX_ONE_PASS");   // =1: whenever possible (tests)
       const bool force = e3 && e3[0] == '1';
-      // a ragged last quad only idles a few waves; below ~16 d-tiles the two-pass sweeps (more waves
-      // per CU) are as fast or faster (measured: ne30x72x2 0.137 vs 0.156 ms, ne30x72x4 0.223 vs 0.203)
-      const bool quad_op = force ? ndt_ >= 4 : (ndt_ >= 16 || (quad && ndt_ >= 8));
+      // a ragged last quad only idles a few waves.  The one-pass sweep runs one wave per SIMD, which
+      // pays once there is enough work: measured break-even near 1.2e7 elements per field
+      // (ne30x72x2, 7e6: 0.137 ms two-pass vs 0.156; ne30x72x4, 1.4e7: 0.223 vs 0.203;
+      // ne120x72x2, 1.1e8: 1.44 vs 1.18)
+      const bool quad_op = ndt_ >= 4 && (force || (double)pl->N * (double)D >= 1.2e7);
       if (quad_op && !(e2 && e2[0] == '1')) {
         const size_t need_cs = (size_t)pl->cgroups * ndt_ * 14 * 64 * 8;
         size_t fr = 0, tot = 0;

@@ -368,7 +368,8 @@ def _one_pass_expected():
 
 @pytest.fixture
 def force_one_pass(monkeypatch):
-    """the one-pass form is normally reserved for >= 16 d-tiles; the parity tests use it on small shapes"""
+    """the one-pass form is normally reserved for >= 1.2e7 elements per field; the parity tests use it on
+    small shapes"""
     import os
     if os.environ.get("TEMX_TWO_PASS") != "1":
         monkeypatch.setenv("TEMX_ONE_PASS", "1")
