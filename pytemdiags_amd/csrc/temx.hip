@@ -1425,8 +1425,13 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
       if (quad_op && !(e2 && e2[0] == '1')) {
         const size_t need_cs = (size_t)pl->cgroups * ndt_ * 14 * 64 * 8;
         size_t fr = 0, tot = 0;
-        if (pl->csum.bytes >= need_cs ||
-            (hipMemGetInfo(&fr, &tot) == hipSuccess && need_cs < fr / 2 && pl->csum.ensure(need_cs) == TEMX_OK)) {
+        bool have = pl->csum.bytes >= need_cs;
+        if (!have && hipMemGetInfo(&fr, &tot) == hipSuccess && need_cs < fr / 2 && pl->csum.ensure(need_cs) == TEMX_OK) {
+          // lanes beyond a ragged last d-tile are never written but are read (and ignored) by the flux kernel
+          HIPCHK(hipMemset(pl->csum.p, 0, pl->csum.bytes));
+          have = true;
+        }
+        if (have) {
           pl->onepass = true;
           pl->sp_cproj4 = sp_op;
           pl->sp_cflux = choose_split(D, std::max<int64_t>(1, pl->cgroups / (8 / edpw)), pl->num_cu, edpw, TEMX_CLS_MINCHUNK);
