@@ -97,8 +97,9 @@ def main():
     ap.add_argument("--no-ncol-extra", action="store_true",
                     help="N > 1, time sharding: skip the extra strong-scaling run of the same job ncol-sharded "
                          "over RCCL (reported as \"ncol_sharded\", not the metric)")
-    ap.add_argument("--also", default="ne30x72x1",
-                    help="comma list of extra (small) workloads timed after the main one, N=1 only")
+    ap.add_argument("--also", default="ne30x72x1,ne30x72x91,ne240x128x1:f32",
+                    help="comma list of the other BASELINE.json shapes, timed after the main one at N=1 "
+                         "(shape[:f32|f64]; ne30x72x91 is one rank's block of the 730-snapshot config)")
     args = ap.parse_args()
     if args.two_pass:
         os.environ["TEMX_TWO_PASS"] = "1"
@@ -274,27 +275,38 @@ def main():
         # other BASELINE.json shapes, same pipeline, reported beside the headline (not the metric)
         rec["other_workloads"] = {}
         for wl in [w for w in args.also.split(",") if w]:
-            ne2, nlev2, nt2 = parse_workload(wl)
-            lat2, lon2 = synth.cubed_sphere_gll(ne2)
-            plev2 = synth.pressure_levels(nlev2)
-            p2 = engine.Plan(lat2, lat_zm, K_HARM - 1, device=local_rank)
-            p2.set_tem(nlev2, nt2, plev2 * 100)
-            f2 = engine.synth_fields(local_rank, lat2, lon2, plev2, nt2, dtype=tdtype, seed=0)
-            o2 = p2._alloc_results(False)
-            for _ in range(5):
-                p2.tem_run(*f2, out=o2)
-            torch.cuda.synchronize()
-            reps = 50
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                p2.tem_run(*f2, out=o2)
-            torch.cuda.synchronize()
-            dt2 = (time.perf_counter() - t0) / reps
-            pts2 = lat2.size * nlev2 * nt2
-            rec["other_workloads"][wl] = {"ms_per_step": dt2 * 1e3, "grid_points_per_s": pts2 / dt2,
-                                          "frac_of_fp64_roofline": pts2 / dt2 / (PEAK_F64_TFLOPS * 1e12 / FLOPS_PER_PT)}
-            p2.close()
-            del f2, o2
+            name, _, dt_s = wl.partition(":")                 # "ne240x128x1:f32" -> shape, input dtype
+            dt2_t = {"": tdtype, "f64": torch.float64, "f32": torch.float32}[dt_s]
+            ne2, nlev2, nt2 = parse_workload(name)
+            try:
+                lat2, lon2 = synth.cubed_sphere_gll(ne2)
+                plev2 = synth.pressure_levels(nlev2)
+                p2 = engine.Plan(lat2, lat_zm, K_HARM - 1, device=local_rank)
+                p2.set_tem(nlev2, nt2, plev2 * 100)
+                f2 = engine.synth_fields(local_rank, lat2, lon2, plev2, nt2, dtype=dt2_t, seed=0)
+                o2 = p2._alloc_results(False)
+                for _ in range(3):
+                    p2.tem_run(*f2, out=o2)
+                torch.cuda.synchronize()
+                reps, t0 = 0, time.perf_counter()
+                while reps < 5 or (time.perf_counter() - t0 < 0.3 and reps < 200):
+                    p2.tem_run(*f2, out=o2)
+                    reps += 1
+                    if reps % 10 == 0:
+                        torch.cuda.synchronize()
+                torch.cuda.synchronize()
+                dt2 = (time.perf_counter() - t0) / reps
+                pts2 = lat2.size * nlev2 * nt2
+                rec["other_workloads"][wl] = {
+                    "ms_per_step": dt2 * 1e3, "grid_points_per_s": pts2 / dt2, "reps": reps,
+                    "sweeps": ("generic", "mirror-paired", "latitude-class")[p2.sweep_mode]
+                              + (", one pass" if p2.one_pass else ""),
+                    "frac_of_fp64_roofline": pts2 / dt2 / (PEAK_F64_TFLOPS * 1e12 / FLOPS_PER_PT)}
+                p2.close()
+                del f2, o2
+            except Exception as e:  # noqa: BLE001 - an extra shape must not cost the metric line
+                rec["other_workloads"][wl] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         del fields
