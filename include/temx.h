@@ -177,6 +177,13 @@ int temx_tem_run(temx_plan* plan, const void* ua, const void* va, const void* ta
 int temx_tem_eddy(temx_plan* plan, const void* ua, const void* va, const void* ta,
                   const void* wap, int dtype, double* const* eddy_ptrs_host, void* stream);
 
+/* The same seven arrays for the native rows [row0, row0 + nrows) only (row0 a multiple of 16), written
+ * compactly as [nrows][nlev][nt]: lets a caller stream the native-grid attributes of a large run to
+ * the host or to a file chunk by chunk with bounded device memory. */
+int temx_tem_eddy_rows(temx_plan* plan, const void* ua, const void* va, const void* ta, const void* wap,
+                       int dtype, int64_t row0, int64_t nrows, double* const* eddy_ptrs_host /* [7], host array */,
+                       void* stream);
+
 /* ---- tracer TEM (Abalos+ 2017): replaces the tracer parts of _decompose_zm_eddy, _compute_fluxes,
  * _compute_derivatives (tem_diagnostics.py:532-538, 560-570, 602-611) and etfy ... qtendwtem
  * (:801-991) for ONE tracer q [ncol][D].  Needs the plan state of a preceding temx_tem_run /

@@ -53,6 +53,7 @@ SIGNATURES = [
     ("temx_tem_stage3", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("temx_tem_run", _i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     ("temx_tem_eddy", _i, [_vp, _vp, _vp, _vp, _vp, _i, C.POINTER(_vp), _vp]),
+    ("temx_tem_eddy_rows", _i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i64, C.POINTER(_vp), _vp]),
     ("temx_tracer_stage1", _i, [_vp, _vp, _i, _vp, _vp]),
     ("temx_tracer_stage2", _i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     ("temx_tracer_stage3", _i, [_vp, _vp, _vp, _vp, _vp]),

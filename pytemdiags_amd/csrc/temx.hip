@@ -385,15 +385,21 @@ static int launch_eddy_t(temx_plan* pl, const FieldPtrs<4>& fp, const double* C,
   }
 }
 
-static int launch_recon(temx_plan* pl, int64_t D, const double* C, double* out, hipStream_t st) {
-  Split sp = choose_split(D, pl->nchunk, 2 * pl->num_cu);
+// native-grid reconstruction out[row][d] = sum_l Y0[row0 + row][l] C[l][d] for rows [row0, row0 + nrows),
+// row0 a multiple of 16 (whole chunks of the blocked Y0 copy); out is compact [nrows][D]
+static int launch_recon(temx_plan* pl, int64_t D, const double* C, double* out, hipStream_t st,
+                        int64_t row0 = 0, int64_t nrows = -1) {
+  if (nrows < 0) nrows = pl->N - row0;
+  const int64_t nch = (nrows + 15) / 16;
+  const double* yb0 = pl->yblk.d() + (row0 / 4) * pl->stride * 16;
+  Split sp = choose_split(D, nch, 2 * pl->num_cu);
   dim3 grid(sp.grid), block(256);
 #define TEMX_LR(TBv, tboff, Cs, acc)                                                                  \
   do {                                                                                                \
     auto kern = recon_kernel<TBv>;                                                                    \
     const size_t lds = (size_t)4 * TBv * 64 * sizeof(double);                                         \
-    hipLaunchKernelGGL(kern, grid, block, lds, st, pl->N, D, pl->yblk.d(), pl->stride, tboff,         \
-                       pl->nchunk, Cs, out, acc, sp.nsplit, sp.ndt);                                  \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, nrows, D, yb0, pl->stride, tboff,                  \
+                       nch, Cs, out, acc, sp.nsplit, sp.ndt);                                         \
   } while (0)
   if (pl->large) {   // one pass per slice of 64 harmonics, accumulating into out
     for (int sl = 0; sl < pl->nslice; ++sl) TEMX_LR(16, 16 * sl, C + (int64_t)64 * sl * D, sl > 0 ? 1 : 0);
@@ -1513,12 +1519,13 @@ static int large_ws(temx_plan* pl) {
 }
 
 static int launch_eddy_from_xbar(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, const FieldPtrs<4>& xb,
-                                 const double* colscale, const EddyOut& eo, hipStream_t st) {
+                                 const double* colscale, const EddyOut& eo, hipStream_t st, int64_t nrows = -1) {
+  if (nrows < 0) nrows = pl->N;
   dim3 grid((unsigned)(pl->num_cu * 8)), block(256);
   if (dtype == TEMX_F64)
-    hipLaunchKernelGGL(eddy_from_xbar_kernel<double>, grid, block, 0, st, fp, xb, pl->N, pl->D, colscale, eo);
+    hipLaunchKernelGGL(eddy_from_xbar_kernel<double>, grid, block, 0, st, fp, xb, nrows, pl->D, colscale, eo);
   else if (dtype == TEMX_F32)
-    hipLaunchKernelGGL(eddy_from_xbar_kernel<float>, grid, block, 0, st, fp, xb, pl->N, pl->D, colscale, eo);
+    hipLaunchKernelGGL(eddy_from_xbar_kernel<float>, grid, block, 0, st, fp, xb, nrows, pl->D, colscale, eo);
   else
     return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
   HIPCHK(hipGetLastError());
@@ -1619,6 +1626,35 @@ int temx_tem_eddy(temx_plan* pl, const void* ua, const void* va, const void* ta,
                                  pl->colscale.d(), eo, S_(stream));
   }
   return run_eddy<0>(pl, four(ua, va, ta, wap), dtype, pl->C4.d(), nullptr, &eo, S_(stream));
+}
+
+int temx_tem_eddy_rows(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap,
+                       int dtype, int64_t row0, int64_t nrows, double* const* eddy_ptrs_host, void* stream) {
+  int rc = tem_ready(pl);
+  if (rc) return rc;
+  if (!ua || !va || !ta || !wap || !eddy_ptrs_host) return fail(TEMX_EINVAL, "null argument");
+  if (row0 < 0 || nrows < 1 || row0 + nrows > pl->N || (row0 & 15))
+    return fail(TEMX_EINVAL, "row range [%lld, %lld) must lie inside the grid and start at a multiple of 16",
+                (long long)row0, (long long)(row0 + nrows));
+  if (dtype != TEMX_F64 && dtype != TEMX_F32) return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
+  HIPCHK(hipSetDevice(pl->device));
+  hipStream_t st = S_(stream);
+  const int64_t D = pl->D, nd = nrows * D;
+  // native zonal means of the rows (coefficients of the last temx_tem_stage2), then elementwise eddies
+  DevBuf& ws = pl->opC;                       // operator-API workspace doubles as the row-chunk buffer
+  if ((rc = ws.ensure((size_t)4 * nd * 8))) return rc;
+  FieldPtrs<4> xb, fp;
+  const void* src[4] = {ua, va, ta, wap};
+  const size_t es = dtype == TEMX_F64 ? 8 : 4;
+  for (int f = 0; f < 4; ++f) {
+    double* o = ws.d() + (int64_t)f * nd;
+    if ((rc = launch_recon(pl, D, pl->C4.d() + (int64_t)f * pl->K4 * D, o, st, row0, nrows))) return rc;
+    xb.p[f] = o;
+    fp.p[f] = static_cast<const char*>(src[f]) + (size_t)row0 * D * es;
+  }
+  EddyOut eo;
+  for (int i = 0; i < TEMX_NEDDY; ++i) eo.p[i] = eddy_ptrs_host[i];
+  return launch_eddy_from_xbar(pl, fp, dtype, xb, pl->colscale.d(), eo, st, nrows);
 }
 
 // ---- tracer TEM -----------------------------------------------------------------------------------

@@ -199,6 +199,22 @@ class Plan:
         check(self.lib.temx_tem_eddy(self._h, _ptr(u), _ptr(v), _ptr(t), _ptr(w), dt, ptrs, self._stream()))
         return outs
 
+    def tem_eddy_rows(self, ua, va, ta, wap, row0, nrows, names=_lib.EDDY_NAMES):
+        """The native-grid eddies / products of rows [row0, row0 + nrows) only (row0 % 16 == 0), compact
+        ``[nrows][nlev][nt]`` tensors: bounded device memory for streaming large runs."""
+        (u, v, t, w), dt = self._four(ua, va, ta, wap)
+        outs = {}
+        ptrs = (C.c_void_p * len(_lib.EDDY_NAMES))()
+        for i, n in enumerate(_lib.EDDY_NAMES):
+            if n in names:
+                outs[n] = torch.empty((int(nrows), self.nlev, self.nt), dtype=torch.float64, device=self.device)
+                ptrs[i] = outs[n].data_ptr()
+            else:
+                ptrs[i] = None
+        check(self.lib.temx_tem_eddy_rows(self._h, _ptr(u), _ptr(v), _ptr(t), _ptr(w), dt, int(row0), int(nrows),
+                                          ptrs, self._stream()))
+        return outs
+
     # ---- tracer TEM (one tracer at a time; needs a preceding tem_run on the same fields) ----
     def _three(self, q, va, wap):
         if self.D is None:

@@ -248,6 +248,23 @@ class TEMDiagnostics:
             self._eddy = self.ZM._plan.tem_eddy(*self._dev_fields)
         return self._wrap(self._eddy[name], name, src_var, native=True)
 
+    def iter_native(self, names=_lib.EDDY_NAMES, chunk_cols=65536):
+        """Stream the native-grid attributes (``up vp thetap wapp upvp upwapp vptp``,
+        tem_diagnostics.py:420-433) in blocks of columns instead of materialising ``[ncol][plev][time]``
+        arrays whole: yields ``(col0, col1, {name: ndarray[col1 - col0, plev, time]})`` with the dtype the
+        corresponding property would have.  Device memory: one block of seven arrays."""
+        chunk = max(16, (int(chunk_cols) // 16) * 16)
+        src = {"up": "ua", "vp": "va", "thetap": "ta", "wapp": "wap", "upvp": "ua", "upwapp": "ua", "vptp": "va"}
+        for c0 in range(0, self.NCOL, chunk):
+            c1 = min(self.NCOL, c0 + chunk)
+            blk = self.ZM._plan.tem_eddy_rows(*self._dev_fields, c0, c1 - c0, names=tuple(names))
+            out = {}
+            for n, v in blk.items():
+                a = v.cpu().numpy()
+                dt = np.float64 if n in _F64_ALWAYS else self._np_dtype(src[n])
+                out[n] = a.astype(np.float64 if dt == np.float64 else np.float32, copy=False)
+            yield c0, c1, out
+
     # ---- getters (tem_diagnostics.py:412-487) ----
     ub = property(lambda s: s._zonal("ub", "ua"))
     vb = property(lambda s: s._zonal("vb", "va"))

@@ -242,3 +242,23 @@ def test_to_netcdf_round_trip(tmp_path):
     assert {"etfy", "etfz", "etdiv", "qtendetfd", "qtendvtem", "qtendwtem", "dqp_dp", "qpvp"} <= set(dq)
     assert fieldnorm_err(dq["etdiv"][1], g["q1_res_etdiv"]) <= 1e-10
     assert dq["qpvp"][0] == ("ncol", "plev", "time")
+
+
+def test_native_attributes_stream_in_column_blocks():
+    """iter_native / temx_tem_eddy_rows: the native-grid attributes block by block equal the whole arrays
+    (streaming them for large runs with bounded device memory)."""
+    from pytemdiags_amd import TEMDiagnostics, LabeledArray
+    g = load("tem_ne4_30x1_f32")
+    tem = TEMDiagnostics(labeled(g, "ua"), labeled(g, "va"), labeled(g, "ta"), labeled(g, "wap"),
+                         LabeledArray(g["lat"], ("ncol",)), debug_level=0)
+    whole = {n: vals(getattr(tem, n)) for n in NATIVE}
+    seen = 0
+    for c0, c1, blk in tem.iter_native(chunk_cols=200):          # 192-column blocks, ragged last one
+        assert c0 == seen and c0 % 16 == 0 and set(blk) == set(NATIVE)
+        for n in NATIVE:
+            assert blk[n].dtype == whole[n].dtype and blk[n].shape == (c1 - c0, 30, 1)
+            np.testing.assert_allclose(blk[n], whole[n][c0:c1], rtol=0, atol=1e-6 * np.max(np.abs(whole[n])))
+        seen = c1
+    assert seen == 866
+    for n in NATIVE:
+        assert fieldnorm_err(whole[n], g["nat_" + n]) <= 2e-5
