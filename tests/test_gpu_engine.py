@@ -247,3 +247,24 @@ def test_one_pass_class_path_vs_reference_golden(eng, one_pass, monkeypatch):
         e = fieldnorm_err(zon[i], g["zm_" + n])
         assert e <= TOL64, (n, e)
     plan.close()
+
+
+@pytest.mark.parametrize("L", [25, 100, 250, 450])
+def test_known_answers_over_the_reference_range_of_L(eng, L):
+    """The asserts of the reference's own test_zonal_mean (tests_sph_zonal_mean.py:297-477, L from 25 to
+    450 on an ne30 grid): the zonal mean of Y_2^1-like and sin(lon) fields vanishes, Y_2^0 is reproduced,
+    lat^2 + 1 is approximated (it is not band limited).  L > 63 runs the sliced large-L path."""
+    from pytemdiags_amd import synth
+    lat, lon = synth.cubed_sphere_gll(30)
+    lat_out = np.linspace(-89.5, 89.5, 180)
+    phi, lam, po = np.deg2rad(lat), np.deg2rad(lon), np.deg2rad(lat_out)
+    y20 = 0.25 * np.sqrt(5 / np.pi) * (3 * np.sin(phi) ** 2 - 1)
+    y21 = -0.5 * np.sqrt(15 / (2 * np.pi)) * np.sin(phi) * np.cos(phi) * np.cos(lam)
+    A = np.stack([y20, y21, np.sin(lam), phi ** 2 + 1], 1)
+    plan = eng.Plan(lat, lat_out, L)
+    zm = plan.zonal_mean(dev(A)).cpu().numpy()
+    assert not plan.status()
+    assert np.max(np.abs(zm[:, 0] - 0.25 * np.sqrt(5 / np.pi) * (3 * np.sin(po) ** 2 - 1))) < 1e-9
+    assert np.max(np.abs(zm[:, 1])) < 1e-9 and np.max(np.abs(zm[:, 2])) < 1e-9
+    assert np.max(np.abs(zm[:, 3] - (po ** 2 + 1))) < 0.1
+    plan.close()
