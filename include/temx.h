@@ -89,8 +89,9 @@ int temx_device_count(void);
  * projection kernel, and (unless TEMX_DEFER_FINALIZE) factorises G on the host (Cholesky),
  * which replaces lstsq(Y0, I_N) (sph_zonal_mean.py:389): pinv(Y0) = G^-1 Y0^T.
  * lat_deg_host[ncol], lat_out_deg_host[M] in degrees.  L <= 511.  Up to L = 63 (K <= 64) the TEM
- * sweeps are the fused kernels; larger L runs the same pipeline as 64-harmonic slices (sliced
- * projections, accumulating native reconstructions, an elementwise eddy-product pass).
+ * sweeps are the fused kernels; larger L runs in 64-harmonic slices: on grids with latitude classes
+ * and K <= 256 the fields are swept once for per-class sums and the slices work on those sums,
+ * otherwise sliced projections, accumulating native reconstructions and an elementwise pass.
  * The sweeps come in three forms, chosen here from the latitudes alone (same operator, results equal
  * up to rounding; temx_plan_sweep_mode tells which):
  *   latitude-class  columns that share |lat| share a basis row (cubed-sphere: 16 per class, lat-lon:

@@ -96,13 +96,16 @@ __global__ void cls_basis_kernel(const double* __restrict__ xc, int64_t ncls, in
 // d-tile) in csum: with them flux_cls_kernel gets the eddy-product sums of a class algebraically
 // (x-bar is constant inside a class side), so the fields are read ONCE.  Needs work cuts at group
 // boundaries.
-template <typename T, int NF, int NFW, int TBS, int WPS, int PD, bool OP>
+// PROJ = false (with OP): only the class sums are produced -- the sliced large-L class path projects
+// them afterwards, 64 harmonics at a time (sums_project_kernel).
+template <typename T, int NF, int NFW, int TBS, int WPS, int PD, bool OP, bool PROJ = true>
 __global__ void __launch_bounds__(256, WPS)
 project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict__ ycls,
                    const int4* __restrict__ crow, const int2* __restrict__ csplit,
                    const double* __restrict__ colscale, int sfield, double* __restrict__ partial, int nsplit,
                    int ndt, double* __restrict__ csum) {
   static_assert(!OP || (NF == 4 && NFW == 4), "one-pass sums need all four fields in one wave");
+  static_assert(PROJ || OP, "a sweep must produce something");
   constexpr int DPW = 4 * NFW / NF;
   constexpr int NB = 2 * TBS;
   constexpr int YE = NB * 16;
@@ -200,9 +203,11 @@ project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
         for (int f = 0; f < NFW; ++f) sN[f] += wt[j] * (double)xb[P][j][f];
     }
     if (flags & CLS_LAST) {
+      if constexpr (PROJ) {
 #pragma unroll
-      for (int j = 0; j < YJ; ++j)
-        if (lane + 64 * j < YE) yst[lane + 64 * j] = ys[j];
+        for (int j = 0; j < YJ; ++j)
+          if (lane + 64 * j < YE) yst[lane + 64 * j] = ys[j];
+      }
       if constexpr (OP) {                     // 7 sums per side of this (group, d-tile), theta-scaled
         if (dvalid) {
           // row s of the record = {northern, southern} value of sum s per lane: 7 stores of 16 B
@@ -217,25 +222,28 @@ project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
         for (int q = 0; q < 3; ++q) qN[q] = qS[q] = 0.0;
       }
       ++grp;
-      load_ys(grp);                           // ycls is padded by one group
-      double ss[NFW], dd[NFW];
+      if constexpr (PROJ) {
+        load_ys(grp);                         // ycls is padded by one group
+        double ss[NFW], dd[NFW];
 #pragma unroll
-      for (int f = 0; f < NFW; ++f) {
-        ss[f] = (sN[f] + sS[f]) * sc[f];
-        dd[f] = (sN[f] - sS[f]) * sc[f];
-        sN[f] = sS[f] = 0.0;
+        for (int f = 0; f < NFW; ++f) {
+          ss[f] = (sN[f] + sS[f]) * sc[f];
+          dd[f] = (sN[f] - sS[f]) * sc[f];
+        }
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+          const double ya = yst[t * 16 + yoff];
+#pragma unroll
+          for (int f = 0; f < NFW; ++f) acc[f][t] = TEMX_MFMA4(ya, t < TBS ? ss[f] : dd[f], acc[f][t]);
+        }
       }
 #pragma unroll
-      for (int t = 0; t < NB; ++t) {
-        const double ya = yst[t * 16 + yoff];
-#pragma unroll
-        for (int f = 0; f < NFW; ++f) acc[f][t] = TEMX_MFMA4(ya, t < TBS ? ss[f] : dd[f], acc[f][t]);
-      }
+      for (int f = 0; f < NFW; ++f) sN[f] = sS[f] = 0.0;
     }
   };
 
   if (b0 < b1) {
-    load_ys(grp);
+    if constexpr (PROJ) load_ys(grp);
     // prologue: X of the first PD - 1 batches (the table is padded, a short list just loads padding)
     rn = crow[(int64_t)b0 * 4 + g];
     {
@@ -265,7 +273,7 @@ project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
   }
 
   // (an empty range still stores its zero slab: the reduction sums every slab)
-  if (dvalid) {
+  if (PROJ && dvalid) {
 #pragma unroll
     for (int f = 0; f < NFW; ++f)
 #pragma unroll
@@ -657,6 +665,219 @@ flux_cls_kernel(int64_t D, int K, int K4, const double* __restrict__ ycls, const
           if ((q * NB + tb) % NP == part && l < K)
             partial[(((int64_t)split * NPR + q) * K + l) * D + d] = red[(q * NB + tb) * 64];
         }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Large-L class path (64 < K <= 256 on a grid with latitude classes): the class sums do not depend on
+// L, so the fields are swept once (project_cls_kernel<.., OP, PROJ = false>) and everything else
+// works on the sums, 64 harmonics (8 even + 8 odd blocks) per slice:
+//   cls_basis_slice_kernel   ycls_l[slice][group][16][16], harmonics 64 s ... 64 s + 63
+//   sums_project_kernel<NQ>  partial[split][q][l - 64 s][d] = sum_c Y_l(c) (S_q,N +- S_q,S) for NQ sums of
+//                            a record (the 4 field sums of csum, or the 3 product sums of pbuf)
+//   flux_large_kernel        xbar at the class latitudes from all slices, algebraic eddy-product sums
+//                            -> pbuf[group][dt][3][64][2]
+// ------------------------------------------------------------------------------------------------
+__global__ void cls_basis_slice_kernel(const double* __restrict__ xc, int64_t ncls, int64_t ncls_pad, int K,
+                                       int l0, const double* __restrict__ norm, double* __restrict__ ycls) {
+  int64_t ci = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (ci >= ncls_pad) return;
+  const bool valid = ci < ncls;
+  const double xv = valid ? xc[ci] : 0.0;
+  double* blk = ycls + (ci >> 2) * (16 * 16);
+  const int k = (int)(ci & 3);
+  double pm1 = 1.0, pc = xv;
+  for (int l = 0; l < l0 + 64; ++l) {
+    double P;
+    if (l == 0) {
+      P = 1.0;
+    } else if (l == 1) {
+      P = xv;
+    } else {
+      double pn = ((2 * l - 1) * xv * pc - (l - 1) * pm1) / l;
+      pm1 = pc;
+      pc = pn;
+      P = pn;
+    }
+    if (l < l0) continue;
+    const double val = (valid && l < K) ? norm[l] * P : 0.0;
+    const int h = (l - l0) >> 1;
+    const int t = ((l - l0) & 1) * 8 + (h >> 2);
+    blk[t * 16 + k * 4 + (h & 3)] = val;
+  }
+}
+
+template <int NQ, int DPW>
+__global__ void __launch_bounds__(512, 2)
+sums_project_kernel(int64_t D, int K, int l0, const double* __restrict__ ycls /* this slice */,
+                    const double* __restrict__ rec /* [group][dt][RS][64][2] */, int RS, int row0,
+                    int64_t ngroups, double* __restrict__ partial, int nsplit, int ndt) {
+  extern __shared__ double lds[];
+  constexpr int TBS = 8, NB = 16, YE = NB * 16, YJ = YE / 64, NP = 8 / DPW;
+  int split, dq;
+  if (!wg_work((ndt + DPW - 1) / DPW, nsplit, split, dq)) return;
+  const int wave = uniform_wave(), lane = threadIdx.x & 63;
+  const int w4 = wave % DPW, part = wave / DPW;
+  const int c = lane & 15, g = lane >> 4;
+  const int dt = dq * DPW + w4;
+  const bool active = dt < ndt;
+  const int64_t d = (int64_t)dt * 16 + c;
+  const bool dvalid = active && d < D;
+  const int64_t sub = (int64_t)split * NP + part, nsub = (int64_t)nsplit * NP;
+  const int g0 = (int)(ngroups * sub / nsub), g1 = (int)(ngroups * (sub + 1) / nsub);
+  double* yst = lds + DPW * NQ * NB * 64 + wave * YE;
+  const uint32_t aoff_p = (uint32_t)(g * 4 + (lane & 3));
+  double acc[NQ][NB];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int t = 0; t < NB; ++t) acc[q][t] = 0.0;
+  double2 sv[2][NQ];
+  double ys[2][YJ];
+  auto load = [&](auto pc, int gi) __attribute__((always_inline)) {
+    constexpr int P = decltype(pc)::value;
+    const double2* base = reinterpret_cast<const double2*>(rec + (((int64_t)gi * ndt + dt) * RS + row0) * 128) + lane;
+#pragma unroll
+    for (int j = 0; j < YJ; ++j) ys[P][j] = (ycls + (int64_t)gi * YE)[lane + 64 * j];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) sv[P][q] = base[q * 64];
+  };
+  auto step = [&](auto pc, int gi) __attribute__((always_inline)) {
+    constexpr int P = decltype(pc)::value;
+    if (gi + 1 < g1) load(std::integral_constant<int, P ^ 1>{}, gi + 1);
+#pragma unroll
+    for (int j = 0; j < YJ; ++j) yst[lane + 64 * j] = ys[P][j];
+#pragma unroll
+    for (int tb = 0; tb < NB; ++tb) {
+      const double ya = yst[tb * 16 + aoff_p];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        acc[q][tb] = TEMX_MFMA4(ya, tb < TBS ? sv[P][q].x + sv[P][q].y : sv[P][q].x - sv[P][q].y, acc[q][tb]);
+    }
+  };
+  if (active && g0 < g1) {
+    load(std::integral_constant<int, 0>{}, g0);
+    for (int gi = g0; gi < g1; gi += 2) {
+      step(std::integral_constant<int, 0>{}, gi);
+      if (gi + 1 < g1) step(std::integral_constant<int, 1>{}, gi + 1);
+    }
+  }
+  __syncthreads();
+  {
+    double* red = lds + (size_t)w4 * (NQ * NB * 64) + lane;
+    for (int pw = 0; pw < NP; ++pw) {
+      if (part == pw) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+          for (int tb = 0; tb < NB; ++tb) {
+            double* r = red + (q * NB + tb) * 64;
+            *r = pw == 0 ? acc[q][tb] : *r + acc[q][tb];
+          }
+      }
+      __syncthreads();
+    }
+    const int Ks = K - l0 < 64 ? K - l0 : 64;
+    if (dvalid) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int tb = 0; tb < NB; ++tb) {
+          const int ll = sym_harm<TBS>(tb, g);          // harmonic inside the slice
+          if ((q * NB + tb) % NP == part && ll < Ks)
+            partial[(((int64_t)split * NQ + q) * Ks + ll) * D + d] = red[(q * NB + tb) * 64];
+        }
+    }
+  }
+}
+
+// one workgroup = one d-tile (8 waves split the class-groups); the coefficients of all NS slices of the
+// four fields stay in LDS (NS * 32 KB)
+template <int NS>
+__global__ void __launch_bounds__(512, 2)
+flux_large_kernel(int64_t D, int K, int K4, const double* __restrict__ ycls_l /* [NS][groups+1][16][16] */,
+                  int64_t gstride /* doubles per slice of ycls_l */, const double* __restrict__ csum,
+                  const double* __restrict__ ccnt, int64_t ngroups, const double* __restrict__ C,
+                  double* __restrict__ pbuf, int nsplit, int ndt) {
+  extern __shared__ double lds[];
+  constexpr int TBS = 8, NB = 16, YE = NB * 16, YJ = YE / 64, NFR = 4;
+  int split, dt;
+  if (!wg_work(ndt, nsplit, split, dt)) return;
+  const int wave = uniform_wave(), lane = threadIdx.x & 63;
+  const int c = lane & 15, g = lane >> 4;
+  const int64_t d = (int64_t)dt * 16 + c;
+  const bool dvalid = d < D;
+  const int64_t dcl = dvalid ? d : D - 1;
+  const int64_t sub = (int64_t)split * 8 + wave, nsub = (int64_t)nsplit * 8;
+  const int g0 = (int)(ngroups * sub / nsub), g1 = (int)(ngroups * (sub + 1) / nsub);
+  // coefficient B operands of every slice: cb[s][f][tb][lane] = C_f[64 s + harm(tb, g)][d]
+  {
+    double* cb = lds + lane;
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int f = 0; f < NFR; ++f) {
+        double v[NB];
+#pragma unroll
+        for (int tb = 0; tb < NB; ++tb) {
+          const int l = 64 * s + sym_harm<TBS>(tb, g);
+          const int lc = l < K ? l : K - 1;
+          v[tb] = C[((int64_t)f * K4 + lc) * D + dcl];
+        }
+#pragma unroll
+        for (int tb = 0; tb < NB; ++tb)
+          cb[((s * NFR + f) * NB + tb) * 64] = 64 * s + sym_harm<TBS>(tb, g) < K ? v[tb] : 0.0;
+      }
+  }
+  int cbi = lane;
+  double* yst = lds + NS * NFR * NB * 64 + wave * YE;
+  const uint32_t aoff_r = (uint32_t)((lane & 3) * 4 + g);
+  for (int gi = g0; gi < g1; ++gi) {
+    const double2* base = reinterpret_cast<const double2*>(csum + (((int64_t)gi * ndt + dt) * 14) * 64) + lane;
+    double2 S[7];
+#pragma unroll
+    for (int s_ = 0; s_ < 7; ++s_) S[s_] = base[s_ * 64];
+    const double nN = ccnt[(int64_t)gi * 8 + g], nS = ccnt[(int64_t)gi * 8 + 4 + g];
+    double E[NFR], O[NFR];
+#pragma unroll
+    for (int f = 0; f < NFR; ++f) E[f] = O[f] = 0.0;
+    for (int s = 0; s < NS; ++s) {
+      double ys[YJ];
+#pragma unroll
+      for (int j = 0; j < YJ; ++j) ys[j] = (ycls_l + s * gstride + (int64_t)gi * YE)[lane + 64 * j];
+#pragma unroll
+      for (int j = 0; j < YJ; ++j) yst[lane + 64 * j] = ys[j];
+      asm volatile("" : "+v"(cbi));
+      const double* cbr = lds + cbi + (size_t)s * (NFR * NB * 64);
+#pragma unroll
+      for (int tb = 0; tb < NB; ++tb) {
+        const double ya = yst[tb * 16 + aoff_r];
+#pragma unroll
+        for (int f = 0; f < NFR; ++f) {
+          if (tb < TBS)
+            E[f] = TEMX_MFMA4(ya, cbr[(f * NB + tb) * 64], E[f]);
+          else
+            O[f] = TEMX_MFMA4(ya, cbr[(f * NB + tb) * 64], O[f]);
+        }
+      }
+    }
+    double2 pr[3];
+    {
+      const double ub = E[0] + O[0], vb = E[1] + O[1], tb_ = E[2] + O[2], wb = E[3] + O[3];
+      pr[0].x = S[4].x - vb * S[0].x - ub * S[1].x + nN * ub * vb;
+      pr[1].x = S[5].x - wb * S[0].x - ub * S[3].x + nN * ub * wb;
+      pr[2].x = S[6].x - tb_ * S[1].x - vb * S[2].x + nN * vb * tb_;
+    }
+    {
+      const double ub = E[0] - O[0], vb = E[1] - O[1], tb_ = E[2] - O[2], wb = E[3] - O[3];
+      pr[0].y = S[4].y - vb * S[0].y - ub * S[1].y + nS * ub * vb;
+      pr[1].y = S[5].y - wb * S[0].y - ub * S[3].y + nS * ub * wb;
+      pr[2].y = S[6].y - tb_ * S[1].y - vb * S[2].y + nS * vb * tb_;
+    }
+    if (dvalid) {
+      double2* o = reinterpret_cast<double2*>(pbuf + (((int64_t)gi * ndt + dt) * 3) * 128) + lane;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) o[q * 64] = pr[q];
     }
   }
 }

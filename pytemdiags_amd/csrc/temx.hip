@@ -118,6 +118,11 @@ struct temx_plan {
   Split sp_cproj4, sp_cproj1, sp_ceddy, sp_cflux;
   // one-pass form of the class path: sweep 1 also stores per-class sums of products (csum), the
   // flux kernel replaces sweep 2 (kernels_cls.hpp)
+  // large-L class path (64 < K <= 256 with latitude classes): class sums first, then sliced work on the sums
+  bool lcls = false, lone = false, xb_valid = false;
+  DevBuf ycls_l, pbuf;
+  int64_t ycls_lstride = 0;
+  Split sp_lflux;
   bool onepass = false, op_valid = false;
   const void* op_ptr[4] = {nullptr, nullptr, nullptr, nullptr};
   int op_dtype = -1;
@@ -757,6 +762,82 @@ static int launch_flux_cls(temx_plan* pl, const double* C, double* partial, cons
   }
 }
 
+// ---- large-L class path ----------------------------------------------------------------------------
+// sweep 1: the class sums of the four fields and of u v, u omega, v T (no projection)
+static int launch_class_sums(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, hipStream_t st) {
+  const Split& sp = pl->sp_cproj4;
+  const int2* cuts = nullptr;
+  if (int rc = class_cuts(pl, sp.nsplit, &cuts, true)) return rc;
+  dim3 grid(sp.grid), block(256);
+#define TEMX_LCS(Tv)                                                                                  \
+  hipLaunchKernelGGL((project_cls_kernel<Tv, 4, 4, 2, TEMX_CLS_OP_WPS, TEMX_CLS_OP_PD, true, false>), grid, block, 0, st, \
+                     fp, pl->D, pl->K, (const double*)nullptr, static_cast<const int4*>(pl->crow.p), cuts,          \
+                     pl->colscale.d(), 2, (double*)nullptr, sp.nsplit, sp.ndt, pl->csum.d())
+  if (dtype == TEMX_F64) TEMX_LCS(double);
+  else if (dtype == TEMX_F32) TEMX_LCS(float);
+  else return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
+#undef TEMX_LCS
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+// B[NQ][K][D] = sum over classes of Y_l (S_N +- S_S) for NQ sums of the records in rec, slice by slice
+template <int NQ>
+static int project_sums(temx_plan* pl, const double* rec, int RS, int row0, double* B, hipStream_t st) {
+  const Split& sp = pl->sp_cflux;
+  const int64_t D = pl->D;
+  dim3 grid(sp.grid), block(512);
+  int rc;
+  for (int sl = 0; sl < pl->nslice; ++sl) {
+    const int Ks = std::min(64, pl->K - 64 * sl);
+#define TEMX_LSP(DPWv)                                                                                \
+  do {                                                                                                \
+    auto kern = sums_project_kernel<NQ, DPWv>;                                                        \
+    const size_t lds = ((size_t)DPWv * NQ * 16 * 64 + 8 * 256) * sizeof(double);                      \
+    static std::atomic<uint64_t> attr_set{0};                                                         \
+    if (int rc_ = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(kern), (int)lds)) \
+      return rc_;                                                                                     \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, D, pl->K, 64 * sl, pl->ycls_l.d() + sl * pl->ycls_lstride, \
+                       rec, RS, row0, pl->cgroups, pl->partial.d(), sp.nsplit, sp.ndt);               \
+  } while (0)
+    switch (sp.dpw) {
+      case 1: TEMX_LSP(1); break;
+      case 2: TEMX_LSP(2); break;
+      default: TEMX_LSP(4); break;
+    }
+#undef TEMX_LSP
+    HIPCHK(hipGetLastError());
+    if ((rc = launch_reduce(pl, pl->partial.d(), sp.nsplit, (int64_t)NQ * Ks * D, pl->Bs.d(), st))) return rc;
+    for (int q = 0; q < NQ; ++q)
+      HIPCHK(hipMemcpyAsync(B + ((int64_t)q * pl->K + 64 * sl) * D, pl->Bs.d() + (int64_t)q * Ks * D,
+                            (size_t)Ks * D * 8, hipMemcpyDeviceToDevice, st));
+  }
+  return TEMX_OK;
+}
+
+static int launch_flux_large(temx_plan* pl, const double* C, hipStream_t st) {
+  const Split& sp = pl->sp_lflux;
+  dim3 grid(sp.grid), block(512);
+#define TEMX_LFL(NSv)                                                                                 \
+  do {                                                                                                \
+    auto kern = flux_large_kernel<NSv>;                                                               \
+    const size_t lds = ((size_t)NSv * 4 * 16 * 64 + 8 * 256) * sizeof(double);                        \
+    static std::atomic<uint64_t> attr_set{0};                                                         \
+    if (int rc_ = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(kern), (int)lds)) \
+      return rc_;                                                                                     \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, pl->D, pl->K, pl->K4, pl->ycls_l.d(), pl->ycls_lstride, \
+                       pl->csum.d(), pl->ccnt.d(), pl->cgroups, C, pl->pbuf.d(), sp.nsplit, sp.ndt);  \
+  } while (0)
+  switch (pl->nslice) {
+    case 2: TEMX_LFL(2); break;
+    case 3: TEMX_LFL(3); break;
+    default: TEMX_LFL(4); break;
+  }
+#undef TEMX_LFL
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
 template <typename T, int NF>
 static int launch_project_sym_t(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t D, const double* colscale,
                                 int sfield, double* partial, const Split& sp, hipStream_t st) {
@@ -1028,6 +1109,8 @@ void temx_plan_destroy(temx_plan* pl) {
   pl->ycls.release();
   pl->csum.release();
   pl->ccnt.release();
+  pl->ycls_l.release();
+  pl->pbuf.release();
   pl->gblk.release();
   pl->ypblk.release();
   for (auto& kv : pl->csplits) kv.second.release();
@@ -1150,12 +1233,32 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
     const char* e0 = getenv("TEMX_NO_SYM");
     const char* e1 = getenv("TEMX_NO_CLS");
     ClassTables ct;
-    if (!pl->large && !(flags & (TEMX_NO_SYMMETRY | TEMX_NO_CLASSES)) && !(e0 && e0[0] == '1') &&
+    if ((!pl->large || pl->K <= 256) && !(flags & (TEMX_NO_SYMMETRY | TEMX_NO_CLASSES)) && !(e0 && e0[0] == '1') &&
         !(e1 && e1[0] == '1') && build_classes(lat_deg_host, ncol, ct)) {
       if ((rc = upload(pl->crow, ct.crow.data(), ct.crow.size() * sizeof(int)))) return bail(rc);
       if ((rc = upload(pl->ccnt, ct.cnt.data(), ct.cnt.size() * 8))) return bail(rc);
       DevBuf xc;
       if ((rc = upload(xc, ct.xc.data(), ct.xc.size() * 8))) return bail(rc);
+      if (pl->large) {   // class sums first, sliced basis at the class latitudes (kernels_cls.hpp)
+        const int64_t npad = (ct.ngroups + 1) * 4;
+        pl->ycls_lstride = (ct.ngroups + 1) * 256;
+        rc = pl->ycls_l.ensure((size_t)pl->nslice * pl->ycls_lstride * 8);
+        if (rc) {
+          xc.release();
+          return bail(rc);
+        }
+        for (int sl = 0; sl < pl->nslice; ++sl)
+          hipLaunchKernelGGL(cls_basis_slice_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, 0, xc.d(),
+                             ct.ncls, npad, pl->K, 64 * sl, pl->norm.d(), pl->ycls_l.d() + sl * pl->ycls_lstride);
+        hipError_t e2 = hipDeviceSynchronize();
+        xc.release();
+        if (e2 != hipSuccess) return bail(fail(TEMX_EHIP, "class basis kernel failed: %s", hipGetErrorString(e2)));
+        pl->gbatch0 = std::move(ct.gbatch0);
+        pl->cgroups = ct.ngroups;
+        pl->cbatches = ct.nbatch;
+        pl->ncls = ct.ncls;
+        pl->lcls = true;
+      } else {
       rc = pl->ycls.ensure((size_t)(ct.ngroups + 1) * 2 * pl->TBS * 16 * 8);
       if (rc) {
         xc.release();
@@ -1172,6 +1275,7 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
       pl->cbatches = ct.nbatch;
       pl->ncls = ct.ncls;
       pl->cls = true;
+      }
     }
   }
   // mirror pairing (kernels_sym.hpp): ~46 % fewer MFMAs on equatorially symmetric grids
@@ -1208,9 +1312,13 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
 
 int temx_plan_is_paired(const temx_plan* pl) { return pl && (pl->sym || pl->cls) ? 1 : 0; }
 
-int temx_plan_sweep_mode(const temx_plan* pl) { return !pl ? -1 : (pl->cls ? 2 : (pl->sym ? 1 : 0)); }
+int temx_plan_sweep_mode(const temx_plan* pl) {
+  return !pl ? -1 : ((pl->cls || (pl->lcls && pl->lone)) ? 2 : (pl->sym ? 1 : 0));
+}
 
-int temx_plan_one_pass(const temx_plan* pl) { return pl && pl->cls && pl->onepass ? 1 : 0; }
+int temx_plan_one_pass(const temx_plan* pl) {
+  return pl && ((pl->cls && pl->onepass) || (pl->lcls && pl->lone)) ? 1 : 0;
+}
 
 int temx_plan_finalize(temx_plan* pl, const double* G_host) {
   if (!pl) return fail(TEMX_EINVAL, "null plan");
@@ -1404,6 +1512,29 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
     const size_t need3 = (size_t)pl->sp_proj1.nsplit * 3 * 64 * D * 8;
     if ((rc = pl->partial.ensure(std::max(need3, pl->partial.bytes)))) return rc;
   }
+  pl->lone = false;
+  pl->xb_valid = false;
+  if (pl->lcls) {    // large-L class path: class sums first (kernels_cls.hpp), if they fit
+    const char* e2 = getenv("TEMX_TWO_PASS");
+    const size_t need_cs = (size_t)pl->cgroups * ndt_ * 14 * 64 * 8, need_pb = (size_t)pl->cgroups * ndt_ * 3 * 128 * 8;
+    size_t fr = 0, tot = 0;
+    if (ndt_ >= 4 && !(e2 && e2[0] == '1') && hipMemGetInfo(&fr, &tot) == hipSuccess &&
+        (pl->csum.bytes >= need_cs || need_cs + need_pb < fr / 2) && pl->csum.ensure(need_cs) == TEMX_OK &&
+        pl->pbuf.ensure(need_pb) == TEMX_OK) {
+      HIPCHK(hipMemset(pl->csum.p, 0, pl->csum.bytes));
+      HIPCHK(hipMemset(pl->pbuf.p, 0, pl->pbuf.bytes));
+      const int64_t cunits = std::max<int64_t>(1, pl->cbatches / 4);
+      pl->sp_cproj4 = choose_split(D, cunits, TEMX_CLS_OP_WPS * pl->num_cu, 4, 8);
+      pl->sp_cflux = choose_split(D, std::max<int64_t>(1, pl->cgroups / (8 / edpw)), pl->num_cu, edpw, TEMX_CLS_MINCHUNK);
+      pl->sp_lflux = choose_split(D, std::max<int64_t>(1, pl->cgroups / 8), pl->num_cu, 1, TEMX_CLS_MINCHUNK);
+      const size_t need4 = (size_t)pl->sp_cflux.nsplit * 4 * 64 * D * 8;
+      if ((rc = pl->partial.ensure(std::max(need4, pl->partial.bytes)))) return rc;
+      if ((rc = pl->Bs.ensure((size_t)4 * 64 * D * 8))) return rc;
+      const int2* cuts_unused = nullptr;
+      if ((rc = class_cuts(pl, pl->sp_cproj4.nsplit, &cuts_unused, true))) return rc;
+      pl->lone = true;
+    }
+  }
   if (pl->cls) {
     const bool quad = pick_dpw(ndt_, 4) == 4;
     const int64_t cunits = std::max<int64_t>(1, pl->cbatches / 4);   // work units of ~4 batches (one cubed-sphere class-group)
@@ -1487,6 +1618,13 @@ int temx_tem_stage1(temx_plan* pl, const void* ua, const void* va, const void* t
   hipStream_t st = S_(stream);
   FieldPtrs<4> fp;
   fp.p[0] = ua; fp.p[1] = va; fp.p[2] = ta; fp.p[3] = wap;
+  if (pl->large && pl->lone) {   // class sums first, then their projection slice by slice
+    for (int i = 0; i < 4; ++i) pl->op_ptr[i] = fp.p[i];
+    pl->op_dtype = dtype;
+    pl->op_valid = true;
+    if ((rc = launch_class_sums(pl, fp, dtype, st))) return rc;
+    return project_sums<4>(pl, pl->csum.d(), 7, 0, B4, st);
+  }
   if (pl->large) return project_all<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->sp_proj4, B4, st);
   TimedLaunch tl{};
   time_begin(pl, 0, st, tl);
@@ -1540,6 +1678,18 @@ static FieldPtrs<4> native_means(temx_plan* pl, int a, int b, int c, int d) {
   return xb;
 }
 
+// native zonal means of the four fields from the coefficients of the last solve (large-L paths)
+static int ensure_xb(temx_plan* pl, hipStream_t st) {
+  if (pl->xb_valid) return TEMX_OK;
+  int rc;
+  if ((rc = large_ws(pl))) return rc;
+  const int64_t nd = pl->N * pl->D;
+  for (int f = 0; f < 4; ++f)
+    if ((rc = launch_recon(pl, pl->D, pl->C4.d() + (int64_t)f * pl->K4 * pl->D, pl->XB.d() + f * nd, st))) return rc;
+  pl->xb_valid = true;
+  return TEMX_OK;
+}
+
 static int tem_stage2_large(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, const double* B4, double* B3,
                             hipStream_t st) {
   int rc;
@@ -1554,6 +1704,7 @@ static int tem_stage2_large(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, co
     eo.p[4 + i] = pl->P3.d() + i * nd;
     f3.p[i] = eo.p[4 + i];
   }
+  pl->xb_valid = true;
   if ((rc = launch_eddy_from_xbar(pl, fp, dtype, native_means(pl, 0, 1, 2, 3), pl->colscale.d(), eo, st))) return rc;
   return project_all<3>(pl, f3, TEMX_F64, pl->D, nullptr, -1, pl->sp_proj1, B3, st);
 }
@@ -1565,6 +1716,13 @@ int temx_tem_stage2(temx_plan* pl, const void* ua, const void* va, const void* t
   if (!ua || !va || !ta || !wap || !B4 || !B3) return fail(TEMX_EINVAL, "null argument");
   HIPCHK(hipSetDevice(pl->device));
   hipStream_t st = S_(stream);
+  if (pl->large && pl->lone && pl->op_valid && pl->op_dtype == dtype && pl->op_ptr[0] == ua && pl->op_ptr[1] == va &&
+      pl->op_ptr[2] == ta && pl->op_ptr[3] == wap) {
+    if ((rc = launch_solve(pl, B4, 4, pl->D, pl->C4.d(), pl->zb.d(), st))) return rc;
+    if ((rc = launch_flux_large(pl, pl->C4.d(), st))) return rc;
+    pl->xb_valid = false;          // the native means are not materialised on this path
+    return project_sums<3>(pl, pl->pbuf.d(), 3, 0, B3, st);
+  }
   if (pl->large) return tem_stage2_large(pl, four(ua, va, ta, wap), dtype, B4, B3, st);
   // C = G^-1 B4 and the four zonal means ub vb thetab wapb -> zb[0..3]
   if ((rc = launch_solve(pl, B4, 4, pl->D, pl->C4.d(), pl->zb.d(), st))) return rc;
@@ -1621,7 +1779,7 @@ int temx_tem_eddy(temx_plan* pl, const void* ua, const void* va, const void* ta,
   EddyOut eo;
   for (int i = 0; i < TEMX_NEDDY; ++i) eo.p[i] = eddy_ptrs_host[i];
   if (pl->large) {
-    if (!pl->XB.p) return fail(TEMX_ESTATE, "temx_tem_stage2 has not been called");
+    if ((rc = ensure_xb(pl, S_(stream)))) return rc;
     return launch_eddy_from_xbar(pl, four(ua, va, ta, wap), dtype, native_means(pl, 0, 1, 2, 3),
                                  pl->colscale.d(), eo, S_(stream));
   }
@@ -1699,7 +1857,7 @@ int temx_tracer_stage2(temx_plan* pl, const void* q, const void* va, const void*
   // coefficients: Ct = (C_q, C_v, C_w); qb -> tz[0]
   if ((rc = launch_solve(pl, Bq, 1, pl->D, pl->Ct.d(), pl->tz.d(), st))) return rc;
   if (pl->large) {   // q' v' and q' omega' from the native means of the last temx_tem_stage2
-    if (!pl->XB.p) return fail(TEMX_ESTATE, "temx_tem_stage2 has not been called");
+    if ((rc = ensure_xb(pl, st))) return rc;
     const int64_t nd = pl->N * pl->D;
     if ((rc = launch_recon(pl, pl->D, pl->Ct.d(), pl->XB.d() + 4 * nd, st))) return rc;
     EddyOut eo{};

@@ -44,6 +44,9 @@ def run_case(ne, nlev, nt, L=50, dtype=np.float64, seed=0):
     (16, 24, 3, 50),    # D = 72 again with more columns per split
     (16, 10, 3, 80),    # K = 81 > 64: sliced large-L path, 2 slices
     (16, 6, 2, 130),    # K = 131: 3 slices, ragged last slice
+    (12, 16, 4, 80),    # K = 81, D = 64: large-L class path (class sums first, 2 slices)
+    (16, 20, 5, 130),   # K = 131, D = 100: 3 slices, ragged d-tiles
+    (30, 16, 4, 200),   # K = 201: 4 slices
 ])
 def test_pipeline_shapes_fp64(ne, nlev, nt, L):
     run_case(ne, nlev, nt, L)
@@ -220,11 +223,12 @@ def test_ncol_sharded_flow_emulated_on_one_gpu(symmetric_shards):
         pl.close()
 
 
-def test_large_L_eddies_and_tracer_vs_oracle():
+@pytest.mark.parametrize("nlev,nt", [(9, 2), (16, 4)])      # D = 18: generic sliced path; D = 64: class sums first
+def test_large_L_eddies_and_tracer_vs_oracle(nlev, nt):
     """K > 64 (sliced sweeps): native eddies/products and the tracer TEM against the oracle."""
     from oracle import tem_oracle as orc
     from pytemdiags_amd import _lib, engine, synth
-    ne, nlev, nt, L = 12, 9, 2, 70
+    ne, L = 12, 70
     lat, lon = synth.cubed_sphere_gll(ne)
     plev = synth.pressure_levels(nlev)
     f = synth.analytic_fields(lat, lon, plev, nt, seed=3)
