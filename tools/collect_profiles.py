@@ -1,10 +1,16 @@
 #!/usr/bin/env python3
 """Copy the rocprofv3 / bench outputs of one measurement session from gpurun_out/ into profiles/
 (committed) and derive profiles/traffic.json.  Usage: collect_profiles.py <stats_dir> <pmc_prefix> [round]"""
-import collections, csv, glob, json, shutil, sys
+import collections, csv, glob, json, os, shutil, sys
+
+
+def newest(pattern):     # gpurun merges every session's files into gpurun_out/: take the latest
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 stats, pmc = sys.argv[1], sys.argv[2]
 rnd = sys.argv[3] if len(sys.argv) > 3 else "r01"
-shutil.copy(glob.glob("gpurun_out/%s/*/*_kernel_stats.csv" % stats)[0],
+shutil.copy(newest("gpurun_out/%s/*/*_kernel_stats.csv" % stats),
             "profiles/%s_rocprof_kernel_stats_ne120x72x30.csv" % rnd)
 shutil.copy("gpurun_out/bench_%s.json" % rnd, "profiles/%s_bench_ne120x72x30.json" % rnd)
 for tag, name in (("generic", "generic_sweeps"), ("paired", "paired_sweeps"), ("twopass", "class_two_pass")):
@@ -14,7 +20,7 @@ for tag, name in (("generic", "generic_sweeps"), ("paired", "paired_sweeps"), ("
         pass
 out, tot = [], {}
 for name in ("fetch", "write", "sq"):
-    f = glob.glob("gpurun_out/%s_%s/*/*_counter_collection.csv" % (pmc, name))[0]
+    f = newest("gpurun_out/%s_%s/*/*_counter_collection.csv" % (pmc, name))
     d = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         d[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
