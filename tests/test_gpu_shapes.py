@@ -519,6 +519,8 @@ def test_fuzz_random_grids_and_shapes(seed, monkeypatch):
     nlev = int(rng.integers(2, 24))
     nt = int(rng.integers(1, 9))
     L = int(rng.integers(3, min(63, nuniq // 2)))
+    if nuniq >= 300 and rng.random() < 0.5:                  # the sliced large-L paths (64 < K)
+        L = int(rng.integers(64, min(160, nuniq // 2)))
     dtype = np.float32 if rng.random() < 0.25 else np.float64
     if rng.random() < 0.5:
         monkeypatch.setenv("TEMX_ONE_PASS", "1")
