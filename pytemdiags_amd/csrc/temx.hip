@@ -1514,6 +1514,7 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
   }
   pl->lone = false;
   pl->xb_valid = false;
+  pl->op_valid = false;      // class sums of an earlier configuration are void
   if (pl->lcls) {    // large-L class path: class sums first (kernels_cls.hpp), if they fit
     const char* e2 = getenv("TEMX_TWO_PASS");
     const size_t need_cs = (size_t)pl->cgroups * ndt_ * 14 * 64 * 8, need_pb = (size_t)pl->cgroups * ndt_ * 3 * 128 * 8;
