@@ -158,7 +158,10 @@ int temx_tem_stage1(temx_plan* plan, const void* ua, const void* va, const void*
 
 /* stage 2: coefficients C = G^-1 B4, zonal means ub vb thetab wapb (Y0p C), then one sweep that
  * reconstructs the native-grid means (Y0 C), forms the eddies x' = x - xbar (:517-529), the
- * products u'v', u'w', v'theta' (:547-555) and projects them: B3[3][K][D] raw sums. */
+ * products u'v', u'w', v'theta' (:547-555) and projects them: B3[3][K][D] raw sums.
+ * Call it with the fields of the preceding temx_tem_stage1, unchanged: in the one-pass form of the
+ * class path (temx_plan_one_pass) it works from the per-class sums stage 1 stored in the plan and does
+ * not read the fields at all; given other pointers it falls back to the sweep described above. */
 int temx_tem_stage2(temx_plan* plan, const void* ua, const void* va, const void* ta,
                     const void* wap, int dtype, const double* B4, double* B3, void* stream);
 
