@@ -534,7 +534,7 @@ def test_fuzz_random_grids_and_shapes(seed, monkeypatch):
     # the oracle and the engine both solve the K x K normal equations; give the tolerance the room
     # the conditioning of this random grid asks for
     cond = np.linalg.cond(ref.ZM.Y0.T @ ref.ZM.Y0)
-    tol = (1e-10 if dtype == np.float64 else 2e-5) * max(1.0, cond / 1e4)
+    tol = (1e-10 if dtype == np.float64 else 2e-5) * max(1.0, cond / 2e3)     # (the BASELINE grids: cond <= 20)
     info = (seed, lat.size, nlev, nt, L, dtype.__name__, plan.sweep_mode, plan.one_pass, "cond %.1e" % cond)
     for i, n in enumerate(_lib.RESULT_NAMES):
         e = fieldnorm_err(res[i].cpu().numpy(), getattr(ref, n)())
