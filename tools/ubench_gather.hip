@@ -14,7 +14,7 @@
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s\n", hipGetErrorString(e_)); exit(1); } } while (0)
 
 // ST > 0: after every 64 rows the wave also stores ST x 512 B (the class-sum record of the one-pass sweep)
-template <int W, int RPI, int ST = 0>   // W = doubles per lane per load (1 or 2), RPI = rows per load instruction
+template <int W, int RPI, int ST = 0, int NI = 4>   // W = doubles per lane per load (1 or 2), RPI = rows per load instruction, NI = load instructions per field in flight
 __global__ void __launch_bounds__(256, 2) gather(const double* const* f, const int* rows, int nrows, int D,
                                                  int colgroups, double* sink, double* out = nullptr) {
   constexpr int LPR = 64 / RPI;            // lanes per row
@@ -30,21 +30,26 @@ __global__ void __launch_bounds__(256, 2) gather(const double* const* f, const i
   const int r0 = (int)((long)nrows * rw / nrw), r1 = (int)((long)nrows * (rw + 1) / nrw);
   long rec = ((long)rw * colgroups + cg) * ((nrows / nrw) / 64 + 2);
   int since = 0;
-  for (int r = r0; r + 4 * RPI <= r1; r += 4 * RPI) {      // 4 instructions per field in flight
-    int rr[4];
-    for (int j = 0; j < 4; ++j) rr[j] = rows[r + j * RPI + g];
+  for (int r = r0; r + NI * RPI <= r1; r += NI * RPI) {      // NI instructions per field in flight
+    int rr[NI];
+    for (int j = 0; j < NI; ++j) rr[j] = rows[r + j * RPI + g];
     for (int i = 0; i < 4; ++i)
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NI; ++j) {
         const double* p = f[i] + (long)rr[j] * D + col;
         if (W == 1) s[i][0] += *p;
         else { double2 v = *reinterpret_cast<const double2*>(p); s[i][0] += v.x; s[i][1] += v.y; }
       }
     if (ST > 0) {
-      since += 4 * RPI;
+      since += NI * RPI;
       if (since >= 64) {
         since = 0;
-        double* o = out + rec * (ST * 64) + lane;
-        for (int k = 0; k < ST; ++k) o[k * 64] = s[k & 3][0] + k;
+        if (ST == 7) {          // the same bytes as 7 x 16-byte pairs (what the one-pass sweep stores)
+          double2* o2 = reinterpret_cast<double2*>(out + rec * (14 * 64)) + lane;
+          for (int k = 0; k < 7; ++k) o2[k * 64] = make_double2(s[k & 3][0] + k, s[k & 3][0] - k);
+        } else {
+          double* o = out + rec * (ST * 64) + lane;
+          for (int k = 0; k < ST; ++k) o[k * 64] = s[k & 3][0] + k;
+        }
         ++rec;
       }
     }
@@ -105,6 +110,9 @@ int main() {
     run("C: 16 B/lane, 2 rows x 512 B per instruction", gather<2, 2>, 64);
     run("D: 8 B/lane, 1 row x 512 B per instruction", gather<1, 1>, 64);
     run_st("E: as A + 14 x 512 B stored per 64 rows", gather<1, 4, 14>, 16);
+    run_st("F: as A + 7 x 1 KB (16 B/lane) per 64 rows", gather<1, 4, 7>, 16);
+    run_st("G: as F, 8 load instructions per field in flight", gather<1, 4, 7, 8>, 16);
+    run_st("H: as F, 16 load instructions per field in flight", gather<1, 4, 7, 16>, 16);
     CHK(hipFree(rows));
     CHK(hipFree(outbuf));
   }
