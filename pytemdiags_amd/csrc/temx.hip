@@ -206,15 +206,17 @@ static int set_ginv(temx_plan* pl, const double* Gi_host) {
   return upload_blocks(pl->gblk, Gp.data(), 4 * pl->TB, pl->K, pl->TB);
 }
 
+constexpr size_t kMaxTimedLaunches = 256;   // enough for an average; bounds the events a long run creates
+
 static void time_begin(temx_plan* pl, int which, hipStream_t st, TimedLaunch& tl) {
-  (void)which;
-  if (!pl->timing) return;
+  tl.a = tl.b = nullptr;
+  if (!pl->timing || pl->timed[which].size() >= kMaxTimedLaunches) return;
   (void)hipEventCreate(&tl.a);
   (void)hipEventCreate(&tl.b);
   (void)hipEventRecord(tl.a, st);
 }
 static void time_end(temx_plan* pl, int which, hipStream_t st, TimedLaunch& tl) {
-  if (!pl->timing) return;
+  if (!pl->timing || tl.a == nullptr) return;
   (void)hipEventRecord(tl.b, st);
   pl->timed[which].push_back(tl);
 }
