@@ -9,17 +9,23 @@ fields already resident in HBM.  Plan build (basis + Gram + Cholesky) is timed s
 
 N = 1   : the workload BASELINE.json's target is quoted on, ne120 (777602 columns) x 72 lev x 30
           snapshots, fp64, on one GPU.
-N > 1   : launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`,
-          one rank per GPU over RCCL.  Default `--shard time`: every rank holds its own block of
-          30 snapshots of the same grid (weak scaling, no data-path collective).  `--shard ncol`:
-          the one ne120x72x30 job is split by columns with an all-reduce of the zonal sums
-          (strong scaling).
+N > 1   : one rank per GPU over RCCL, launched by `python -m torch.distributed.run --nproc-per-node N
+          ... bench.py --gpus N`; invoked directly (`python bench.py --gpus N`) it starts that
+          launcher itself as a child process, before anything touches the GPU, and returns its
+          exit code.  Default `--shard time`: every rank holds its own block of 30 snapshots of
+          the same grid (weak scaling, no data-path collective); the same job ncol-sharded (one
+          ne120x72x30 block in total, columns split in whole latitude classes, the zonal sums
+          all-reduced over RCCL: strong scaling) is timed afterwards and reported beside it as
+          "ncol_sharded".  `--shard ncol` makes that the metric.
 Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -78,11 +84,44 @@ def cpu_baseline_and_parity(plan_factory, lat, lon, plev, nt_s, device):
                       "factorised numpy restatement, %.1f s" % (0, lat.size, len(plev), nt_s, t_cpu)}, err, bad, one_pass
 
 
+def cpu_baseline_config1_literal():
+    """BASELINE configs[0] (ne4 x 30 x 1), the oracle in literal-association mode: dense
+    lstsq(Y0, I_N) and (Y . Y0inv) . A -- the reference's own operation order
+    (sph_zonal_mean.py:389, :251), the only config where that O(N^2) form is feasible."""
+    from oracle import tem_oracle as orc
+    from pytemdiags_amd import synth
+    lat, lon = synth.cubed_sphere_gll(4)
+    plev = synth.pressure_levels(30)
+    f = synth.analytic_fields(lat, lon, plev, 1, seed=0)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        orc.TEMOracle(*f, lat, plev, mode="literal").results()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": lat.size * 30 / best, "unit": "grid-points/s", "kind": "port", "seconds": best,
+            "sample": "configs[0] ne4 (866 cols) x 30 lev x 1, oracle in literal mode: lstsq(Y0, I_N) and "
+                      "(Y Y0inv) A as the reference associates them; best of 3"}
+
+
+def self_launch(argv, ngpus):
+    """`python bench.py --gpus N` without a launcher: become the parent of torch.distributed.run.
+    Nothing here has touched the GPU (no HIP call, no torch.cuda query)."""
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="ne120x72x30")
     ap.add_argument("--shard", choices=["time", "ncol"], default="time")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
@@ -97,9 +136,12 @@ def main():
     ap.add_argument("--no-ncol-extra", action="store_true",
                     help="N > 1, time sharding: skip the extra strong-scaling run of the same job ncol-sharded "
                          "over RCCL (reported as \"ncol_sharded\", not the metric)")
-    ap.add_argument("--also", default="ne30x72x1,ne30x72x91,ne240x128x1:f32",
+    ap.add_argument("--also", default="ne30x72x1,ne30x72x91,ne240x128x1:f32,ne120x72x30:f64:generic",
                     help="comma list of the other BASELINE.json shapes, timed after the main one at N=1 "
-                         "(shape[:f32|f64]; ne30x72x91 is one rank's block of the 730-snapshot config)")
+                         "(shape[:f32|f64][:generic]; ne30x72x91 is one rank's block of the 730-snapshot config; "
+                         ":generic forces the generic sweeps -- what a grid without repeated latitudes gets)")
+    ap.add_argument("--stall-timeout", type=float, default=240.0,
+                    help="N > 1: seconds the extra ncol-sharded run may take before the watchdog reports it stalled")
     args = ap.parse_args()
     if args.two_pass:
         os.environ["TEMX_TWO_PASS"] = "1"
@@ -107,9 +149,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))      # child ranks print the line; same exit code
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        sys.exit("bench.py --gpus %d but WORLD_SIZE=%d: launch one rank per GPU" % (args.gpus, world))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
     # TEMX_BENCH_BACKEND=gloo rehearses the N > 1 control flow with several ranks on one GPU
@@ -176,11 +219,16 @@ def main():
         step()
     barrier()
     plan.kernel_timing(True)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # the library launches on torch's current stream
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    ev[0].record()
+    for i in range(args.steps):
         step()
+        ev[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     nonfinite = plan.status()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -207,6 +255,9 @@ def main():
                    "sweeps": ("generic", "mirror-paired", "latitude-class")[plan.sweep_mode]
                              + (", one pass" if plan.one_pass else ""),
                    "mirror_paired_sweeps": bool(plan.paired)},
+        # per-step HIP-event times of the same K steps (this rank): SURVEY 8(d) quotes the median of >= 20
+        "ms_per_step_median": median_ms, "ms_per_step_min": step_ms[0], "ms_per_step_max": step_ms[-1],
+        "value_at_median": pts_job / (median_ms * 1e-3),
         "plan_build_s": plan_s,
         # dense-operator roofline of SURVEY 8(d): max(64 B / 8 TB/s, 1122 flop / 78.6 TF) per point.  The
         # latitude-class sweeps do the MFMA work per class, not per column, so on grids with repeated
@@ -224,15 +275,16 @@ def main():
         if plan.one_pass and nproj:
             # one-pass class path: the dominant kernel is sweep 1 (the only read of the fields)
             gbs_p = 4 * esize * pts_rank / (proj_ms * 1e-3) / 1e9
-            rec["roofline"] = {"kernel": "project_cls_kernel, one-pass form (theta + class sums of the fields and of u v, "
-                                         "u omega, v theta + 4 class projections)",
+            rec["roofline"] = {"kernel": "project_cls_kernel, one-pass form (theta + class sums of the fields, centred "
+                                         "class co-moments of u v, u omega, v theta + 7 class projections)",
                                "bound": "hbm", "achieved": gbs_p, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": gbs_p / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": proj_ms,
                                "launches": nproj,
                                "algorithmic": "4 fields x %d B per grid point (the one compulsory read of u, v, T, omega) x "
-                                              "%d points per launch; the kernel also stores 14 class sums per class-group "
-                                              "and d-tile (see traffic)" % (esize, pts_rank)}
-            rec["roofline_flux"] = {"kernel": "flux_cls_kernel (class reconstructions, algebraic eddy-product sums, "
+                                              "%d points per launch; the kernel also stores the 4 field sums of every "
+                                              "latitude-class side (8 x 512 B per class-group and d-tile, see traffic)"
+                                              % (esize, pts_rank)}
+            rec["roofline_flux"] = {"kernel": "flux_cls_kernel (class reconstructions, n (m_u - ub)(m_v - vb) per class side, "
                                               "3 class projections)", "avg_launch_ms": eddy_ms, "launches": neddy}
         elif plan.sweep_mode == 2:
             gbs_e = 4 * esize * pts_rank / (eddy_ms * 1e-3) / 1e9
@@ -262,6 +314,8 @@ def main():
                         and j.get("sweeps", "mirror-paired") == rec["config"]["sweeps"]):
                     rec["roofline"]["traffic"] = j.get("project_kernel_hbm_bytes_per_launch" if plan.one_pass
                                                        else "eddy_kernel_hbm_bytes_per_launch")
+                    rec["roofline"]["traffic_source"] = ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                         "passes of this command (tools/profile_session.sh), not this run")
             except Exception:
                 pass
     if nproj and not rec["config"]["sweeps"].endswith("one pass"):
@@ -275,15 +329,18 @@ def main():
         # other BASELINE.json shapes, same pipeline, reported beside the headline (not the metric)
         rec["other_workloads"] = {}
         for wl in [w for w in args.also.split(",") if w]:
-            name, _, dt_s = wl.partition(":")                 # "ne240x128x1:f32" -> shape, input dtype
+            parts = wl.split(":")                             # "ne240x128x1:f32[:generic]" -> shape, input dtype, sweeps
+            name, dt_s = parts[0], (parts[1] if len(parts) > 1 else "")
+            generic = "generic" in parts[2:]
             dt2_t = {"": tdtype, "f64": torch.float64, "f32": torch.float32}[dt_s]
             ne2, nlev2, nt2 = parse_workload(name)
             try:
                 lat2, lon2 = synth.cubed_sphere_gll(ne2)
                 plev2 = synth.pressure_levels(nlev2)
-                p2 = engine.Plan(lat2, lat_zm, K_HARM - 1, device=local_rank)
+                p2 = engine.Plan(lat2, lat_zm, K_HARM - 1, device=local_rank, symmetry=not generic)
                 p2.set_tem(nlev2, nt2, plev2 * 100)
-                f2 = engine.synth_fields(local_rank, lat2, lon2, plev2, nt2, dtype=dt2_t, seed=0)
+                same = name == args.workload and dt2_t == tdtype       # the headline's own fields: reuse them
+                f2 = fields if same else engine.synth_fields(local_rank, lat2, lon2, plev2, nt2, dtype=dt2_t, seed=0)
                 o2 = p2._alloc_results(False)
                 for _ in range(3):
                     p2.tem_run(*f2, out=o2)
@@ -299,6 +356,7 @@ def main():
                 pts2 = lat2.size * nlev2 * nt2
                 rec["other_workloads"][wl] = {
                     "ms_per_step": dt2 * 1e3, "grid_points_per_s": pts2 / dt2, "reps": reps,
+                    "plan_symmetry": not generic,
                     "sweeps": ("generic", "mirror-paired", "latitude-class")[p2.sweep_mode]
                               + (", one pass" if p2.one_pass else ""),
                     "frac_of_fp64_roofline": pts2 / dt2 / (PEAK_F64_TFLOPS * 1e12 / FLOPS_PER_PT)}
@@ -318,6 +376,10 @@ def main():
                                 classes=not args.no_classes), lat, lon, plev, args.cpu_sample_nt, local_rank)
         cb["sample"] = cb["sample"].replace("ne0", "ne%d" % ne)
         rec["cpu_baseline"] = cb
+        try:
+            rec["cpu_baseline_config1_literal"] = cpu_baseline_config1_literal()
+        except Exception as e:  # noqa: BLE001 - the extra baseline must not cost the metric line
+            rec["cpu_baseline_config1_literal"] = {"error": "%s: %s" % (type(e).__name__, e)}
         rec["parity_vs_oracle_on_sample"] = {"max_field_normalised_err": err, "tolerance": 1e-10,
                                             "ok": bool(err <= 1e-10 and not bad), "one_pass": bool(op_s)}
     plan.close()
@@ -326,16 +388,18 @@ def main():
         # BASELINE config 4: the same job (one ne120x72x30 block in total) with the columns sharded over
         # the ranks and the zonal sums all-reduced over RCCL/xGMI -- strong scaling, reported beside
         # the metric.  A watchdog prints the main record and leaves if a collective stalls.
-        import signal
-
-        def _stalled(signum, frame):
-            rec["ncol_sharded"] = {"error": "timed out"}
+        # A collective that never completes blocks inside C code, where no Python signal handler runs:
+        # the watchdog is a daemon thread; it prints the record with the error and ends the rank with a
+        # non-zero exit code (the stall is a failure; its cause is to be found from the logs).
+        def _stalled():
+            rec["ncol_sharded"] = {"error": "stalled: no result after %.0f s" % args.stall_timeout}
             if rank == 0:
                 print(json.dumps(rec), flush=True)
-            os._exit(0)
+            os._exit(3)
 
-        signal.signal(signal.SIGALRM, _stalled)
-        signal.alarm(240)
+        watchdog = threading.Timer(args.stall_timeout, _stalled)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             del fields, out
             torch.cuda.empty_cache()
@@ -358,7 +422,7 @@ def main():
             bad3 = p3.status()
             rec["ncol_sharded"] = {
                 "scaling": "strong", "value": ncol * nlev * nt * args.steps / e3, "unit": "grid-points/s",
-                "ms_per_step": e3 / args.steps * 1e3, "n_gpus": world,
+                "ms_per_step": e3 / args.steps * 1e3, "n_gpus": world, "ranks_in_process_group": dist.get_world_size(),
                 "workload": "ne%d (%d cols) x %d lev x %d snapshots per job, columns sharded in whole latitude classes"
                             % (ne, ncol, nlev, nt),
                 "collectives": "2 RCCL all-reduces per step ([4][K][D] and [3][K][D] fp64 = %d bytes) + the "
@@ -368,8 +432,10 @@ def main():
             p3.close()
         except Exception as e:  # noqa: BLE001 - the metric line must survive a failure of the extra
             rec["ncol_sharded"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        signal.alarm(0)
+        watchdog.cancel()
 
+    if world > 1:
+        rec["process_group"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size()}
     if rank == 0:
         print(json.dumps(rec), flush=True)
     if world > 1:

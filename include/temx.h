@@ -120,12 +120,14 @@ int temx_plan_is_paired(const temx_plan* plan);
 /* 0 generic sweeps, 1 mirror-paired sweeps, 2 latitude-class sweeps (columns that share |lat| share a
  * basis row: cubed-sphere, lat-lon and Gaussian grids; TEMX_NO_CLS=1 in the environment disables) */
 int temx_plan_sweep_mode(const temx_plan* plan);
-/* 1 when (after temx_plan_set_tem) the latitude-class path runs in its one-pass form: sweep 1 also
- * stores per-class sums of u v, u omega, v theta, and the eddy-product sums of a class follow
- * algebraically from them (the zonal mean is constant inside a class side), so temx_tem_stage2 does
- * not read the fields again.  Used from nlev*nt >= 49 and ncol*nlev*nt >= 1.2e7 up (below that the
- * two-pass sweeps are as fast); needs workspace of 14 x 512 B per class-group and d-tile;
- * TEMX_TWO_PASS=1 in the environment disables, TEMX_ONE_PASS=1 lifts the size threshold. */
+/* 1 when (after temx_plan_set_tem) the latitude-class path runs in its one-pass form: sweep 1
+ * (temx_tem_stage1) also accumulates, per latitude class and hemisphere, the sums of u v, u omega and
+ * v theta, projects them next to the four fields, and stores the four field sums of every class side
+ * in the plan; temx_tem_stage2_from_sums then gets the eddy-product sums algebraically (the zonal mean
+ * is constant inside a class side) and the fields are read once.  Used from nlev*nt >= 49 and
+ * ncol*nlev*nt >= 1.2e7 up (below that the two-pass sweeps are as fast); needs workspace of
+ * 8 x 512 B per class-group and d-tile; TEMX_TWO_PASS=1 in the environment disables, TEMX_ONE_PASS=1
+ * lifts the size threshold. */
 int temx_plan_one_pass(const temx_plan* plan);
 
 int temx_get_matrix(temx_plan* plan, int which, double* dst, void* stream);
@@ -159,11 +161,16 @@ int temx_tem_stage1(temx_plan* plan, const void* ua, const void* va, const void*
 /* stage 2: coefficients C = G^-1 B4, zonal means ub vb thetab wapb (Y0p C), then one sweep that
  * reconstructs the native-grid means (Y0 C), forms the eddies x' = x - xbar (:517-529), the
  * products u'v', u'w', v'theta' (:547-555) and projects them: B3[3][K][D] raw sums.
- * Call it with the fields of the preceding temx_tem_stage1, unchanged: in the one-pass form of the
- * class path (temx_plan_one_pass) it works from the per-class sums stage 1 stored in the plan and does
- * not read the fields at all; given other pointers it falls back to the sweep described above. */
+ * Always reads the four fields it is given (they need not be the arrays stage 1 saw, nor unchanged). */
 int temx_tem_stage2(temx_plan* plan, const void* ua, const void* va, const void* ta,
                     const void* wap, int dtype, const double* B4, double* B3, void* stream);
+
+/* stage 2 of the one-pass class path (temx_plan_one_pass(plan) == 1): the same B3, from the per-class
+ * sums the LATEST temx_tem_stage1 on this plan left in the plan's workspace -- no field is read.  The
+ * contract is explicit: the result describes the fields that stage 1 call was given, as they were
+ * then.  TEMX_ESTATE when the plan is not in one-pass form or no stage 1 has run since
+ * temx_plan_set_tem.  B4 is that stage 1's output (all-reduced over the ranks when ncol-sharded). */
+int temx_tem_stage2_from_sums(temx_plan* plan, const double* B4, double* B3, void* stream);
 
 /* stage 3: flux zonal means (:549-557), the derivatives / psi / integral of
  * _compute_derivatives (:574-599) and the ten diagnostics (:615-797) in one fused epilogue.
@@ -171,7 +178,8 @@ int temx_tem_stage2(temx_plan* plan, const void* ua, const void* va, const void*
 int temx_tem_stage3(temx_plan* plan, const double* B3, double* results, double* zonal,
                     void* stream);
 
-/* all three stages with plan-owned B4/B3 (single-GPU / time-sharded use). */
+/* all three stages with plan-owned B4/B3 (single-GPU / time-sharded use); stage 2 in its from-sums
+ * form when the plan runs the one-pass class path. */
 int temx_tem_run(temx_plan* plan, const void* ua, const void* va, const void* ta,
                  const void* wap, int dtype, double* results, double* zonal, void* stream);
 

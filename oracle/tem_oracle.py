@@ -217,7 +217,7 @@ class TEMOracle:
     """
 
     def __init__(self, ua, va, ta, wap, lat_native, plev, p0=P0, zm_dlat=1, L=50,
-                 zm_pole_points=False, mode="literal", basis="scipy", q=None):
+                 zm_pole_points=False, mode="literal", basis="scipy", q=None, weights=None):
         ua, va, ta, wap = (np.asarray(x) for x in (ua, va, ta, wap))
         plev = np.asarray(plev)
         self.q = [] if q is None else [np.asarray(x) for x in (q if isinstance(q, (list, tuple)) else [q])]
@@ -234,7 +234,9 @@ class TEMOracle:
         self.lat = zm_latitudes(zm_dlat, zm_pole_points)         # :388-396
         self.f = (2 * Om * np.sin(self.lat * np.pi / 180))[:, None, None]   # :401, :405
         self.coslat = np.cos(self.lat * np.pi / 180)             # :402
-        self.ZM = ZonalAverager(lat_native, self.lat, L, mode=mode, basis=basis)   # :243-248
+        # `weights` is not an argument of the reference's TEMDiagnostics (:243-248 build the averager
+        # without them); it lets the tests run the pipeline on an averager in weights mode
+        self.ZM = ZonalAverager(lat_native, self.lat, L, weights=weights, mode=mode, basis=basis)   # :243-248
         zm, zmn = self.ZM.zonal_mean, self.ZM.zonal_mean_native
 
         # theta = T (p0/p)^k   (:498); einsum with the fp64 p promotes theta to fp64 (Q5)

@@ -50,6 +50,7 @@ SIGNATURES = [
     ("temx_plan_set_tem", _i, [_vp, _i, _i64, _dp, C.c_double]),
     ("temx_tem_stage1", _i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     ("temx_tem_stage2", _i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    ("temx_tem_stage2_from_sums", _i, [_vp, _vp, _vp, _vp]),
     ("temx_tem_stage3", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("temx_tem_run", _i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     ("temx_tem_eddy", _i, [_vp, _vp, _vp, _vp, _vp, _i, C.POINTER(_vp), _vp]),

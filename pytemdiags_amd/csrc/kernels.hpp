@@ -261,21 +261,24 @@ project_kernel(FieldPtrs<NF> fp, int64_t N, int64_t D, int K, const double* __re
 // A block owns 16 consecutive entries; its 256 threads are 16 entries x 16 split lanes, so small
 // problems (few entries, hundreds of splits) still spread over hundreds of blocks.  Each split lane
 // sums its splits in ascending order, the 16 lane sums are combined in a fixed order.
+// Slab sp starts at partial + sp * stride (stride >= n: a sweep may interleave other slabs);
+// `addend` (NULL or [n]) is added last.
 __global__ void __launch_bounds__(256)
-reduce_partials_kernel(const double* __restrict__ partial, int nsplit, int64_t n,
-                       double* __restrict__ B, int* __restrict__ flag) {
+reduce_partials_kernel(const double* __restrict__ partial, int nsplit, int64_t stride, int64_t n,
+                       const double* __restrict__ addend, double* __restrict__ B, int* __restrict__ flag) {
   __shared__ double sh[16][17];
   const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int64_t idx = (int64_t)blockIdx.x * 16 + e;
   double s = 0.0;
   if (idx < n)
-    for (int sp = sl; sp < nsplit; sp += 16) s += partial[(int64_t)sp * n + idx];
+    for (int sp = sl; sp < nsplit; sp += 16) s += partial[(int64_t)sp * stride + idx];
   sh[sl][e] = s;
   __syncthreads();
   if (sl == 0 && idx < n) {
     double t = 0.0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) t += sh[j][e];
+    if (addend != nullptr) t += addend[idx];
     B[idx] = t;
     if (!(fabs(t) <= 1.79769313486231570815e308)) atomicOr(flag, 1);
   }
@@ -285,16 +288,17 @@ reduce_partials_kernel(const double* __restrict__ partial, int nsplit, int64_t n
 // the same association as the kernel above (each of its 16 split lanes then holds at most one slab),
 // so both give identical bits.
 __global__ void __launch_bounds__(256)
-reduce_partials_flat_kernel(const double* __restrict__ partial, int nsplit, int64_t n,
-                            double* __restrict__ B, int* __restrict__ flag) {
+reduce_partials_flat_kernel(const double* __restrict__ partial, int nsplit, int64_t stride, int64_t n,
+                            const double* __restrict__ addend, double* __restrict__ B, int* __restrict__ flag) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n) return;
   double v[16];
 #pragma unroll
-  for (int sp = 0; sp < 16; ++sp) v[sp] = partial[(int64_t)(sp < nsplit ? sp : 0) * n + idx];
+  for (int sp = 0; sp < 16; ++sp) v[sp] = partial[(int64_t)(sp < nsplit ? sp : 0) * stride + idx];
   double t = 0.0;
 #pragma unroll
   for (int sp = 0; sp < 16; ++sp) t += sp < nsplit ? v[sp] : 0.0;
+  if (addend != nullptr) t += addend[idx];
   B[idx] = t;
   if (!(fabs(t) <= 1.79769313486231570815e308)) atomicOr(flag, 1);
 }

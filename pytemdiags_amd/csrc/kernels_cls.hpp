@@ -26,12 +26,16 @@
 // batch further.
 //
 // One-pass form (project_cls_kernel<.., OP = true> + flux_cls_kernel): inside a class side xbar is a
-// constant, so   sum (u - ub)(v - vb) = S_uv - vb S_u - ub S_v + n ub vb.   Sweep 1 also accumulates
-// S_uv, S_uw, S_vT per class and side and stores, per (class-group, d-tile),
-//   csum[group][dt][7][64][2] sums S_u S_v S_theta S_w S_uv S_uw S_vtheta, per lane (= 16 class + column)
-//                             the {northern, southern} pair: 7 x 16-byte stores / loads per lane
-// and flux_cls_kernel turns them into the projected eddy-product sums after the solve: the fields
-// are read once.  Its work cuts are aligned to class-groups (a stored sum must be complete).
+// constant, so   sum (u - ub)(v - vb) = C_uv + n (m_u - ub)(m_v - vb),   m = S / n the side's mean and
+// C_uv = sum (u - m_u)(v - m_v) its centred co-moment.  Sweep 1 also accumulates C_uv, C_uw, C_vT per
+// class and side (about the side's first member, so nothing large cancels).  They enter the projected
+// eddy-product sums only linearly, so sweep 1 projects them itself (seven projections per wave) and
+// stores, per (class-group, d-tile), only the four field sums
+//   csum[group][dt][4][64][2] sums S_u S_v S_theta S_w, per lane (= 16 class + column) the
+//                             {northern, southern} pair: 4 x 16-byte stores / loads per lane
+// from which flux_cls_kernel forms and projects  n (m_u - ub)(m_v - vb)  after the solve: the fields
+// are read once.  Its work cuts are aligned to class-groups (a stored sum must be
+// complete).  The large-L class path (PROJ = false) stores all seven sums (records of 7 pairs).
 #pragma once
 #include "kernels_sym.hpp"
 
@@ -52,7 +56,16 @@ namespace temx {
 #endif
 
 constexpr int CLS_MB = 4;                     // member rows per class and batch
-constexpr int CLS_PADB = 5;                   // batches of padding behind crow (index loads run ahead)
+constexpr int CLS_PADB = 10;                  // batches of padding behind crow (index loads run up to PD + 1 ahead)
+
+// compile-time unrolled loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(f);
+  }
+}
 constexpr int CLS_ROWMASK = 0x0FFFFFFF;
 constexpr int CLS_SOUTH = 1, CLS_FIRST = 2, CLS_LAST = 4;   // flags, stored at bit 28
 
@@ -92,10 +105,10 @@ __global__ void cls_basis_kernel(const double* __restrict__ xc, int64_t ncls, in
 // per-wave configuration has the registers for a deeper ring, which is what short batch lists
 // (small D) need: they are latency, not bandwidth, bound.
 // OP ("one pass", NF = NFW = 4 only): the sweep also accumulates, per class and side, the sums of u v,
-// u omega and v T next to the four field sums and stores the 7 x 2 sums of every (class-group,
-// d-tile) in csum: with them flux_cls_kernel gets the eddy-product sums of a class algebraically
-// (x-bar is constant inside a class side), so the fields are read ONCE.  Needs work cuts at group
-// boundaries.
+// u omega and v T next to the four field sums, projects them like the fields (partial holds NF + 3
+// slabs per split) and stores the 4 x 2 field sums of every (class-group, d-tile) in csum: with them
+// flux_cls_kernel gets the eddy-product sums of a class algebraically (x-bar is constant inside a
+// class side), so the fields are read ONCE.  Needs work cuts at group boundaries.
 // PROJ = false (with OP): only the class sums are produced -- the sliced large-L class path projects
 // them afterwards, 64 harmonics at a time (sums_project_kernel).
 template <typename T, int NF, int NFW, int TBS, int WPS, int PD, bool OP, bool PROJ = true>
@@ -135,15 +148,26 @@ project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
     sc[f] = (colscale != nullptr && f0 + f == sfield) ? colscale[dcl] : 1.0;
     fb[f] = reinterpret_cast<const T*>(fp.p[f0 + f]) + dcl;
   }
-  double acc[NFW][NB];
+  constexpr int NA = (OP && PROJ) ? NFW + 3 : NFW;   // one-pass form: + projections of u v, u omega, v theta
+  constexpr int NFP = (OP && PROJ) ? NF + 3 : NF;    // slabs per split in `partial`
+  constexpr int RS = PROJ ? 4 : 7;                   // {north, south} pairs per csum record
+  double acc[NA][NB];
 #pragma unroll
-  for (int f = 0; f < NFW; ++f)
+  for (int f = 0; f < NA; ++f)
 #pragma unroll
     for (int t = 0; t < NB; ++t) acc[f][t] = 0.0;
   double sN[NFW], sS[NFW];
 #pragma unroll
   for (int f = 0; f < NFW; ++f) sN[f] = sS[f] = 0.0;
   double qN[3] = {0.0, 0.0, 0.0}, qS[3] = {0.0, 0.0, 0.0};   // OP: sums of u v, u omega, v T
+  // CEN (the one-pass form that projects): the sums of a class side are accumulated about the side's
+  // first member x0 -- S~ = sum (x - x0), q~ = sum (u - u0)(v - v0) -- and turned into the true sums
+  // S = S~ + n x0 and the CENTRED co-moments  C_uv = sum (u - m_u)(v - m_v) = q~ - S~_u S~_v / n
+  // (m = S / n) when the class-group is complete.  Unlike S_uv = sum u v, whose eddy part sits under
+  // n ub vb (v theta: a factor 1e4), the co-moments carry no large cancelling term.
+  constexpr bool CEN = OP && PROJ;
+  double x0N[4] = {0.0, 0.0, 0.0, 0.0}, x0S[4] = {0.0, 0.0, 0.0, 0.0}, cntN = 0.0, cntS = 0.0;
+  bool side_open_N = false, side_open_S = false;             // uniform: a batch of that side has been seen
 
   T xb[PD][MB][NFW];
   int er[PD][MB];
@@ -176,7 +200,33 @@ project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
     double wt[MB];                            // padding entries read row 0 and weigh nothing
 #pragma unroll
     for (int j = 0; j < MB; ++j) wt[j] = er[P][j] < 0 ? 0.0 : 1.0;
-    if constexpr (OP) {
+    if constexpr (CEN) {
+      const bool south = (flags & CLS_SOUTH) != 0;
+      double* sx = south ? sS : sN;
+      double* sq = south ? qS : qN;
+      double* x0 = south ? x0S : x0N;
+      double& cnt = south ? cntS : cntN;
+      bool& open = south ? side_open_S : side_open_N;
+      if (!open) {                            // first batch of this side: its first member is the origin
+        open = true;                          // (a padding entry reads row 0: any origin is valid)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) x0[f] = (double)xb[P][0][f];
+      }
+#pragma unroll
+      for (int j = 0; j < MB; ++j) {
+        const double du = (double)xb[P][j][0] - x0[0], dv = (double)xb[P][j][1] - x0[1];
+        const double dt_ = (double)xb[P][j][2] - x0[2], dw = (double)xb[P][j][3] - x0[3];
+        const double u = wt[j] * du, v = wt[j] * dv;
+        sx[0] += u;
+        sx[1] += v;
+        sx[2] += wt[j] * dt_;
+        sx[3] += wt[j] * dw;
+        sq[0] += u * dv;
+        sq[1] += u * dw;
+        sq[2] += v * dt_;
+        cnt += wt[j];
+      }
+    } else if constexpr (OP) {
       double* sx = (flags & CLS_SOUTH) ? sS : sN;
       double* sq = (flags & CLS_SOUTH) ? qS : qN;
 #pragma unroll
@@ -208,34 +258,59 @@ project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
         for (int j = 0; j < YJ; ++j)
           if (lane + 64 * j < YE) yst[lane + 64 * j] = ys[j];
       }
-      if constexpr (OP) {                     // 7 sums per side of this (group, d-tile), theta-scaled
+      if constexpr (CEN) {                    // shifted sums -> centred co-moments and true sums
+        const double rN = cntN > 0.0 ? 1.0 / cntN : 0.0, rS = cntS > 0.0 ? 1.0 / cntS : 0.0;
+        qN[0] -= sN[0] * sN[1] * rN;  qS[0] -= sS[0] * sS[1] * rS;     // u v
+        qN[1] -= sN[0] * sN[3] * rN;  qS[1] -= sS[0] * sS[3] * rS;     // u omega
+        qN[2] -= sN[1] * sN[2] * rN;  qS[2] -= sS[1] * sS[2] * rS;     // v T
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          sN[f] += cntN * x0N[f];
+          sS[f] += cntS * x0S[f];
+        }
+        cntN = cntS = 0.0;
+        side_open_N = side_open_S = false;
+      }
+      if constexpr (OP) {                     // RS sums per side of this (group, d-tile), theta-scaled
         if (dvalid) {
-          // row s of the record = {northern, southern} value of sum s per lane: 7 stores of 16 B
-          double2* o = reinterpret_cast<double2*>(csum + (((int64_t)grp * ndt + dt) * 14) * 64) + lane;
+          // row s of the record = {northern, southern} value of sum s per lane: RS stores of 16 B
+          double2* o = reinterpret_cast<double2*>(csum + (((int64_t)grp * ndt + dt) * (2 * RS)) * 64) + lane;
 #pragma unroll
           for (int f = 0; f < 4; ++f) o[f * 64] = make_double2(sN[f] * sc[f], sS[f] * sc[f]);
-          o[4 * 64] = make_double2(qN[0], qS[0]);
-          o[5 * 64] = make_double2(qN[1], qS[1]);
-          o[6 * 64] = make_double2(qN[2] * sc[2], qS[2] * sc[2]);
+          if constexpr (!PROJ) {              // large-L class path: the product sums are projected later
+            o[4 * 64] = make_double2(qN[0], qS[0]);
+            o[5 * 64] = make_double2(qN[1], qS[1]);
+            o[6 * 64] = make_double2(qN[2] * sc[2], qS[2] * sc[2]);
+          }
         }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) qN[q] = qS[q] = 0.0;
       }
       ++grp;
       if constexpr (PROJ) {
         load_ys(grp);                         // ycls is padded by one group
-        double ss[NFW], dd[NFW];
+        double ss[NA], dd[NA];
 #pragma unroll
         for (int f = 0; f < NFW; ++f) {
           ss[f] = (sN[f] + sS[f]) * sc[f];
           dd[f] = (sN[f] - sS[f]) * sc[f];
         }
+        if constexpr (OP) {                   // the class co-moments are projected like field sums
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            const double qs = q == 2 ? sc[2] : 1.0;
+            ss[NFW + q] = (qN[q] + qS[q]) * qs;
+            dd[NFW + q] = (qN[q] - qS[q]) * qs;
+          }
+        }
 #pragma unroll
         for (int t = 0; t < NB; ++t) {
           const double ya = yst[t * 16 + yoff];
 #pragma unroll
-          for (int f = 0; f < NFW; ++f) acc[f][t] = TEMX_MFMA4(ya, t < TBS ? ss[f] : dd[f], acc[f][t]);
+          for (int f = 0; f < NA; ++f) acc[f][t] = TEMX_MFMA4(ya, t < TBS ? ss[f] : dd[f], acc[f][t]);
         }
+      }
+      if constexpr (OP) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) qN[q] = qS[q] = 0.0;
       }
 #pragma unroll
       for (int f = 0; f < NFW; ++f) sN[f] = sS[f] = 0.0;
@@ -243,43 +318,31 @@ project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
   };
 
   if (b0 < b1) {
+    static_assert(PD + 1 <= CLS_PADB, "crow padding must cover the index prefetch");
     if constexpr (PROJ) load_ys(grp);
     // prologue: X of the first PD - 1 batches (the table is padded, a short list just loads padding)
     rn = crow[(int64_t)b0 * 4 + g];
-    {
+    static_for<PD - 1>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int k = decltype(kc)::value;
       const int4 r0 = rn;
-      rn = crow[(int64_t)(b0 + 1) * 4 + g];
-      issue(std::integral_constant<int, 0>{}, r0);
-    }
-    if constexpr (PD > 2) {
-      const int4 r0 = rn;
-      rn = crow[(int64_t)(b0 + 2) * 4 + g];
-      if (b0 + 1 < b1) issue(std::integral_constant<int, 1>{}, r0);
-    }
-    if constexpr (PD > 3) {
-      const int4 r0 = rn;
-      rn = crow[(int64_t)(b0 + 3) * 4 + g];
-      if (b0 + 2 < b1) issue(std::integral_constant<int, 2>{}, r0);
-    }
-    for (int b = b0; b < b1; b += PD) {
-      step(std::integral_constant<int, 0>{}, b);
-      if constexpr (PD > 1)
-        if (b + 1 < b1) step(std::integral_constant<int, 1>{}, b + 1);
-      if constexpr (PD > 2)
-        if (b + 2 < b1) step(std::integral_constant<int, 2>{}, b + 2);
-      if constexpr (PD > 3)
-        if (b + 3 < b1) step(std::integral_constant<int, 3>{}, b + 3);
-    }
+      rn = crow[(int64_t)(b0 + k + 1) * 4 + g];
+      if (k == 0 || b0 + k < b1) issue(kc, r0);
+    });
+    for (int b = b0; b < b1; b += PD)
+      static_for<PD>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        if (k == 0 || b + k < b1) step(kc, b + k);
+      });
   }
 
   // (an empty range still stores its zero slab: the reduction sums every slab)
   if (PROJ && dvalid) {
 #pragma unroll
-    for (int f = 0; f < NFW; ++f)
+    for (int f = 0; f < NA; ++f)
 #pragma unroll
       for (int t = 0; t < NB; ++t) {
         const int l = sym_harm<TBS>(t, g);
-        if (l < K) partial[(((int64_t)split * NF + f0 + f) * K + l) * D + d] = acc[f][t];
+        if (l < K) partial[(((int64_t)split * NFP + f0 + f) * K + l) * D + d] = acc[f][t];
       }
   }
 }
@@ -521,11 +584,15 @@ eddy_cls_kernel(FieldPtrs<4> fp, int64_t D, int K, int K4, const double* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// flux_cls_kernel: second phase of the one-pass class path.  Per (class-group, d-tile): reconstruct
-// the zonal means at the class latitudes (4 x 14 MFMAs), turn the stored class sums into the sums
-// of the eddy products --
-//     sum (u - ub)(v - vb) = S_uv - vb S_u - ub S_v + n ub vb       (ub, vb constant in a class side)
-// -- and project them (3 x 14 MFMAs).  Reads 14 x 512 B per (group, d-tile) instead of the fields.
+// flux_cls_kernel: second phase of the one-pass class path.  Inside a class side the zonal mean xb is a
+// constant, so with the side's mean m = S / n and its centred co-moment C_uv = sum (u - m_u)(v - m_v)
+//     sum (u - ub)(v - vb) = C_uv + n (m_u - ub)(m_v - vb)          (tem_diagnostics.py:547-557)
+// Sweep 1 projected the co-moments next to the four fields (they enter linearly); this kernel adds the
+// second term, which needs only the four field sums of every class side.  Per (class-group, d-tile):
+// reconstruct the zonal means at the class latitudes (4 x 14 MFMAs), form n (m_u - ub)(m_v - vb)
+// (and the same for u omega, v theta) and project it (3 x 14 MFMAs).  Reads 8 x 512 B per (group,
+// d-tile) instead of the fields; the caller adds the co-moment projections of sweep 1 (launch_reduce
+// with an addend).  No term is a difference of large numbers.
 // ------------------------------------------------------------------------------------------------
 template <int TBS, int DPW>
 __global__ void __launch_bounds__(512, 2)
@@ -577,19 +644,19 @@ flux_cls_kernel(int64_t D, int K, int K4, const double* __restrict__ ycls, const
 #pragma unroll
     for (int t = 0; t < NB; ++t) acc[q][t] = 0.0;
 
-  double sv[2][14], cn[2][2], ys[2][YJ];
+  double sv[2][8], cn[2][2], ys[2][YJ];
   auto load = [&](auto pc, int gi) __attribute__((always_inline)) {
     constexpr int P = decltype(pc)::value;
-    const double2* base = reinterpret_cast<const double2*>(csum + (((int64_t)gi * ndt + (active ? dt : 0)) * 14) * 64) + lane;
+    const double2* base = reinterpret_cast<const double2*>(csum + (((int64_t)gi * ndt + (active ? dt : 0)) * 8) * 64) + lane;
 #pragma unroll
     for (int j = 0; j < YJ; ++j) ys[P][j] = (ycls + (int64_t)gi * YE)[(lane + 64 * j) < YE ? (lane + 64 * j) : 0];
     cn[P][0] = ccnt[(int64_t)gi * 8 + g];
     cn[P][1] = ccnt[(int64_t)gi * 8 + 4 + g];
 #pragma unroll
-    for (int s_ = 0; s_ < 7; ++s_) {
+    for (int s_ = 0; s_ < 4; ++s_) {
       const double2 v2 = base[s_ * 64];
       sv[P][s_] = v2.x;           // northern members
-      sv[P][7 + s_] = v2.y;       // southern members
+      sv[P][4 + s_] = v2.y;       // southern members
     }
   };
   auto step = [&](auto pc, int gi) __attribute__((always_inline)) {
@@ -617,13 +684,16 @@ flux_cls_kernel(int64_t D, int K, int K4, const double* __restrict__ ycls, const
     double pr[2][NPR];
 #pragma unroll
     for (int sd = 0; sd < 2; ++sd) {
-      const double* S = sv[P] + 7 * sd;
-      const double n = cn[P][sd];
-      const double ub = sd ? E[0] - O[0] : E[0] + O[0], vb = sd ? E[1] - O[1] : E[1] + O[1];
-      const double tb_ = sd ? E[2] - O[2] : E[2] + O[2], wb = sd ? E[3] - O[3] : E[3] + O[3];
-      pr[sd][0] = S[4] - vb * S[0] - ub * S[1] + n * ub * vb;      // u'v'
-      pr[sd][1] = S[5] - wb * S[0] - ub * S[3] + n * ub * wb;      // u'omega'
-      pr[sd][2] = S[6] - tb_ * S[1] - vb * S[2] + n * vb * tb_;    // v'theta'
+      const double* S = sv[P] + 4 * sd;
+      const double n = cn[P][sd], rn = n > 0.0 ? 1.0 / n : 0.0;
+      // class-side mean minus the zonal mean at the class latitude (E + O north, E - O south)
+      const double du = S[0] * rn - (sd ? E[0] - O[0] : E[0] + O[0]);
+      const double dv = S[1] * rn - (sd ? E[1] - O[1] : E[1] + O[1]);
+      const double dth = S[2] * rn - (sd ? E[2] - O[2] : E[2] + O[2]);
+      const double dw = S[3] * rn - (sd ? E[3] - O[3] : E[3] + O[3]);
+      pr[sd][0] = n * du * dv;       // sum u'v'     - C_uv
+      pr[sd][1] = n * du * dw;       // sum u'omega' - C_uw
+      pr[sd][2] = n * dv * dth;      // sum v'theta' - C_vtheta
     }
 #pragma unroll
     for (int tb = 0; tb < NB; ++tb) {

@@ -88,6 +88,7 @@ struct temx_plan {
   bool large = false;
   DevBuf Bs, XB, P3;             // large-L path: slice sums, native means [4][N][D], products [3][N][D]
   bool finalized = false;
+  bool weighted = false;      // weights mode (temx_plan_set_weights): projection rows are scaled, reconstruction rows are not
   int rank = 0;               // numerical rank of Y0 (== K unless the pseudo-inverse fallback ran)
   DevBuf x, Y0, yblk, yblk_w, Y0p, G, Ginv, norm, flag;
   DevBuf gblk, ypblk;            // Ginv / Y0p as 4x4 MFMA A-operand blocks (solve_mfma_kernel, K <= 64)
@@ -123,10 +124,10 @@ struct temx_plan {
   DevBuf ycls_l, pbuf;
   int64_t ycls_lstride = 0;
   Split sp_lflux;
+  // op_valid: csum (and Pq) hold the class sums of the latest temx_tem_stage1 on this plan
   bool onepass = false, op_valid = false;
-  const void* op_ptr[4] = {nullptr, nullptr, nullptr, nullptr};
-  int op_dtype = -1;
   DevBuf csum, ccnt;
+  DevBuf Pq;                     // [3][K][D] projections of u v, u omega, v theta accumulated by sweep 1
   // shared workspaces
   DevBuf partial;
   // operator-API workspace (any D)
@@ -302,17 +303,20 @@ static int launch_project(temx_plan* pl, const FieldPtrs<NF>& fp, int dtype, int
   return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
 }
 
+// B[n] = (addend ? addend : 0) + sum over the nsplit slabs; slab sp starts at partial + sp * stride
+// (stride < 0: the slabs are dense, stride = n)
 static int launch_reduce(temx_plan* pl, const double* partial, int nsplit, int64_t n, double* B,
-                         hipStream_t st) {
+                         hipStream_t st, int64_t stride = -1, const double* addend = nullptr) {
+  if (stride < 0) stride = n;
   if (nsplit <= 16 && n >= 32768) {   // many entries, few slabs: one thread per entry (same bits)
     hipLaunchKernelGGL(reduce_partials_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial,
-                       nsplit, n, B, static_cast<int*>(pl->flag.p));
+                       nsplit, stride, n, addend, B, static_cast<int*>(pl->flag.p));
     HIPCHK(hipGetLastError());
     return TEMX_OK;
   }
   const int64_t blocks = (n + 15) / 16;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)blocks), dim3(256), 0, st, partial, nsplit, n, B,
-                     static_cast<int*>(pl->flag.p));
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)blocks), dim3(256), 0, st, partial, nsplit, stride, n,
+                     addend, B, static_cast<int*>(pl->flag.p));
   HIPCHK(hipGetLastError());
   return TEMX_OK;
 }
@@ -533,6 +537,11 @@ static bool build_classes(const double* lat, int64_t N, ClassTables& ct) {
       const int r = order[j];
       (lat[r] < -tol ? c.s : c.n).push_back(r);      // equator columns count as northern
     }
+    // the class sits at the mean |lat| of its members (they agree to within tol): deviations of either
+    // sign, half the size of those from the smallest member
+    long double sum = 0.0L;
+    for (size_t m = i; m < j; ++m) sum += (long double)std::fabs(lat[order[m]]) - (long double)c.alat;
+    c.alat += (double)(sum / (long double)(j - i));
     std::sort(c.n.begin(), c.n.end());
     std::sort(c.s.begin(), c.s.end());
     cls.push_back(std::move(c));
@@ -640,7 +649,25 @@ static int class_cuts(temx_plan* pl, int nsub, const int2** out, bool group_alig
 #ifndef TEMX_CLS_MINCHUNK
 #define TEMX_CLS_MINCHUNK 1
 #endif
+#ifndef TEMX_CLS_OP_PD_F32
+#define TEMX_CLS_OP_PD_F32 6
+#endif
+#ifndef TEMX_CLS_E_PD_F32
+#define TEMX_CLS_E_PD_F32 4
+#endif
+#ifndef TEMX_CLS_Q_PD_F32
+#define TEMX_CLS_Q_PD_F32 4
+#endif
 constexpr int CLS_PROJ_E_WPS = TEMX_CLS_E_WPS, CLS_PROJ_E_PD = TEMX_CLS_E_PD;   // one field per wave
+// X batches a wave of the class project sweep holds (PD - 1 in flight).  A batch of fp32 carries half
+// the bytes of an fp64 one in half the registers, so fp32 inputs get rings twice as deep: the same
+// bytes in flight per wave.
+template <typename T>
+constexpr int cls_proj_pd(bool op, int nfw) {
+  constexpr bool f32 = sizeof(T) == 4;
+  return op ? (f32 ? TEMX_CLS_OP_PD_F32 : TEMX_CLS_OP_PD)
+            : (nfw == 1 ? (f32 ? TEMX_CLS_E_PD_F32 : CLS_PROJ_E_PD) : (f32 ? TEMX_CLS_Q_PD_F32 : 2));
+}
 
 template <typename T, int NF>
 static int launch_project_cls_t(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t D, const double* colscale,
@@ -649,7 +676,7 @@ static int launch_project_cls_t(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t 
   if (int rc = class_cuts(pl, sp.nsplit, &cuts, csum != nullptr)) return rc;
   dim3 grid(sp.grid), block(256);
 #define TEMX_LPC(TBSv, NFWv, WPSv, OPv)                                                             \
-  hipLaunchKernelGGL((project_cls_kernel<T, NF, NFWv, TBSv, WPSv, (OPv ? TEMX_CLS_OP_PD : (NFWv == 1 ? CLS_PROJ_E_PD : 2)), OPv>), grid, block, 0, st, fp, D, pl->K, \
+  hipLaunchKernelGGL((project_cls_kernel<T, NF, NFWv, TBSv, WPSv, cls_proj_pd<T>(OPv, NFWv), OPv>), grid, block, 0, st, fp, D, pl->K, \
                      pl->ycls.d(), static_cast<const int4*>(pl->crow.p), cuts, colscale, sfield,    \
                      partial, sp.nsplit, sp.ndt, csum)
   if constexpr (NF == 4) {
@@ -772,7 +799,7 @@ static int launch_class_sums(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, h
   if (int rc = class_cuts(pl, sp.nsplit, &cuts, true)) return rc;
   dim3 grid(sp.grid), block(256);
 #define TEMX_LCS(Tv)                                                                                  \
-  hipLaunchKernelGGL((project_cls_kernel<Tv, 4, 4, 2, TEMX_CLS_OP_WPS, TEMX_CLS_OP_PD, true, false>), grid, block, 0, st, \
+  hipLaunchKernelGGL((project_cls_kernel<Tv, 4, 4, 2, TEMX_CLS_OP_WPS, cls_proj_pd<Tv>(true, 4), true, false>), grid, block, 0, st, \
                      fp, pl->D, pl->K, (const double*)nullptr, static_cast<const int4*>(pl->crow.p), cuts,          \
                      pl->colscale.d(), 2, (double*)nullptr, sp.nsplit, sp.ndt, pl->csum.d())
   if (dtype == TEMX_F64) TEMX_LCS(double);
@@ -1033,6 +1060,10 @@ static void gradient_table(const std::vector<double>& x, std::vector<double>& ta
   tab[(n - 1) * 3 + 1] = 1.0 / dx[n - 2];
 }
 
+// The fused second sweep reads ONE set of Y0 blocks for the reconstruction and for the projection, so it
+// serves neither K > 64 nor weights mode (projection rows scaled by 4 pi w, reconstruction rows not).
+static inline bool unfused_stage2(const temx_plan* pl) { return pl->large || pl->weighted; }
+
 static inline hipStream_t S_(void* s) { return static_cast<hipStream_t>(s); }
 static inline const Split& eddy_split(const temx_plan* pl) {
   return pl->cls ? pl->sp_ceddy : (pl->sym ? pl->sp_seddy : pl->sp_eddy);
@@ -1111,6 +1142,7 @@ void temx_plan_destroy(temx_plan* pl) {
   pl->ycls.release();
   pl->csum.release();
   pl->ccnt.release();
+  pl->Pq.release();
   pl->ycls_l.release();
   pl->pbuf.release();
   pl->gblk.release();
@@ -1185,7 +1217,7 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
   if ((rc = pl->Y0.ensure((size_t)ncol * pl->K * 8))) return bail(rc);
   // one extra chunk of blocks: the sweeps prefetch A operands one group / step ahead
   if ((rc = pl->yblk.ensure((size_t)(pl->nchunk + 1) * 4 * pl->stride * 16 * 8))) return bail(rc);
-  HIPCHK(hipMemset(pl->yblk.p, 0, pl->yblk.bytes));
+  if (hipMemset(pl->yblk.p, 0, pl->yblk.bytes) != hipSuccess) return bail(fail(TEMX_EHIP, "hipMemset of the Y0 blocks failed"));
   if ((rc = build_basis(pl, nullptr, pl->Y0.d(), pl->yblk.d()))) return bail(rc);
 
   // Y0p on the output latitudes (sph_zonal_mean.py:367-370): same kernel, canonical copy only
@@ -1375,8 +1407,12 @@ int temx_plan_set_weights(temx_plan* pl, const double* w_host) {
   std::vector<double> I((size_t)pl->K * pl->K, 0.0);
   for (int k = 0; k < pl->K; ++k) I[(size_t)k * pl->K + k] = 1.0;
   if (int rcg = set_ginv(pl, I.data())) return rcg;
-  pl->sym = pl->cls = false;      // weighted rows of one latitude no longer share a basis row
+  // weighted rows of one latitude no longer share a basis row: every latitude-structured path is off
+  // (the large-L class path too: its class basis ycls_l is unweighted)
+  pl->sym = pl->cls = pl->lcls = false;
+  pl->lone = pl->onepass = pl->op_valid = pl->xb_valid = false;
   pl->tem = false;                // splits / workspaces belong to the path: set_tem again
+  pl->weighted = true;
   pl->finalized = true;
   return TEMX_OK;
 }
@@ -1460,15 +1496,19 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
   if ((int64_t)nlev * nt >= ((int64_t)1 << 28)) return fail(TEMX_EINVAL, "nlev*nt must be < 2^28");
   if (pl->M < 2) return fail(TEMX_EINVAL, "need at least 2 zonal-mean latitudes");
   HIPCHK(hipSetDevice(pl->device));
+  std::vector<double> p(p_pa_host, p_pa_host + nlev), tab;
+  for (int j = 1; j < nlev; ++j)
+    if (!(p[j] > p[j - 1])) return fail(TEMX_EINVAL, "pressure must be strictly ascending (front end flips)");
+  // a failure below must not leave an earlier configuration half replaced: the plan is unconfigured
+  // (tem_ready fails) until the last allocation has succeeded
+  pl->tem = false;
+  pl->onepass = pl->lone = pl->op_valid = pl->xb_valid = false;
   pl->nlev = nlev;
   pl->nt = nt;
   pl->D = (int64_t)nlev * nt;
   pl->p0 = p0;
   const int M = pl->M;
   const int64_t D = pl->D;
-  std::vector<double> p(p_pa_host, p_pa_host + nlev), tab;
-  for (int j = 1; j < nlev; ++j)
-    if (!(p[j] > p[j - 1])) return fail(TEMX_EINVAL, "pressure must be strictly ascending (front end flips)");
   int rc;
   if ((rc = upload(pl->p, p.data(), (size_t)nlev * 8))) return rc;
   gradient_table(p, tab);
@@ -1510,7 +1550,7 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
   if ((rc = pl->C4.ensure((size_t)4 * pl->K4 * D * 8))) return rc;
   if ((rc = pl->zb.ensure((size_t)8 * M * D * 8))) return rc;
   pl->sp_proj1 = choose_split(D, pl->nchunk, 2 * pl->num_cu);
-  if (pl->large) {   // products are projected three at a time, 64 harmonics per pass
+  if (unfused_stage2(pl)) {   // products are projected three at a time, 64 harmonics per pass
     const size_t need3 = (size_t)pl->sp_proj1.nsplit * 3 * 64 * D * 8;
     if ((rc = pl->partial.ensure(std::max(need3, pl->partial.bytes)))) return rc;
   }
@@ -1550,7 +1590,7 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
                                            pl->sp_cproj1.nsplit}) * pl->K * D * 8;
     if ((rc = pl->partial.ensure(std::max(need3, pl->partial.bytes)))) return rc;
     // one-pass form: quads of d-tiles, enough class-groups per piece for group-aligned cuts to balance,
-    // and room for the class sums (14 x 512 B per class-group and d-tile)
+    // and room for the class sums (8 x 512 B per class-group and d-tile)
     pl->onepass = false;
     pl->op_valid = false;
     {
@@ -1563,7 +1603,7 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
       // ne120x72x2, 1.1e8: 1.44 vs 1.18)
       const bool quad_op = ndt_ >= 4 && (force || (double)pl->N * (double)D >= 1.2e7);
       if (quad_op && !(e2 && e2[0] == '1')) {
-        const size_t need_cs = (size_t)pl->cgroups * ndt_ * 14 * 64 * 8;
+        const size_t need_cs = (size_t)pl->cgroups * ndt_ * 8 * 64 * 8;   // 4 {north, south} pairs per lane
         size_t fr = 0, tot = 0;
         bool have = pl->csum.bytes >= need_cs;
         if (!have && hipMemGetInfo(&fr, &tot) == hipSuccess && need_cs < fr / 2 && pl->csum.ensure(need_cs) == TEMX_OK) {
@@ -1575,8 +1615,9 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
           pl->onepass = true;
           pl->sp_cproj4 = sp_op;
           pl->sp_cflux = choose_split(D, std::max<int64_t>(1, pl->cgroups / (8 / edpw)), pl->num_cu, edpw, TEMX_CLS_MINCHUNK);
-          const size_t need4 = (size_t)std::max(pl->sp_cflux.nsplit * 3, sp_op.nsplit * 4) * pl->K * D * 8;
+          const size_t need4 = (size_t)std::max(pl->sp_cflux.nsplit * 3, sp_op.nsplit * 7) * pl->K * D * 8;
           if ((rc = pl->partial.ensure(std::max(need4, pl->partial.bytes)))) return rc;
+          if ((rc = pl->Pq.ensure((size_t)3 * pl->K * D * 8))) return rc;
         }
       }
     }
@@ -1622,29 +1663,32 @@ int temx_tem_stage1(temx_plan* pl, const void* ua, const void* va, const void* t
   FieldPtrs<4> fp;
   fp.p[0] = ua; fp.p[1] = va; fp.p[2] = ta; fp.p[3] = wap;
   if (pl->large && pl->lone) {   // class sums first, then their projection slice by slice
-    for (int i = 0; i < 4; ++i) pl->op_ptr[i] = fp.p[i];
-    pl->op_dtype = dtype;
-    pl->op_valid = true;
+    pl->op_valid = false;
     if ((rc = launch_class_sums(pl, fp, dtype, st))) return rc;
-    return project_sums<4>(pl, pl->csum.d(), 7, 0, B4, st);
+    if ((rc = project_sums<4>(pl, pl->csum.d(), 7, 0, B4, st))) return rc;
+    pl->op_valid = true;
+    return TEMX_OK;
   }
   if (pl->large) return project_all<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->sp_proj4, B4, st);
   TimedLaunch tl{};
   time_begin(pl, 0, st, tl);
   const bool sp4 = sym_project(pl, 4);
   const Split& sp = pl->cls ? pl->sp_cproj4 : (sp4 ? pl->sp_sproj4 : pl->sp_proj4);
-  if (pl->cls && pl->onepass) {   // remember whose class sums csum holds
-    for (int i = 0; i < 4; ++i) pl->op_ptr[i] = fp.p[i];
-    pl->op_dtype = dtype;
-    pl->op_valid = true;
-  }
+  const bool op = pl->cls && pl->onepass;
+  pl->op_valid = false;
   rc = pl->cls ? launch_project_cls<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->partial.d(), sp, st,
-                                       pl->onepass ? pl->csum.d() : nullptr)
+                                       op ? pl->csum.d() : nullptr)
        : sp4   ? launch_project_sym<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->partial.d(), sp, st)
                : launch_project<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->partial.d(), sp, st);
   time_end(pl, 0, st, tl);
   if (rc) return rc;
-  return launch_reduce(pl, pl->partial.d(), sp.nsplit, (int64_t)4 * pl->K * pl->D, B4, st);
+  const int64_t KD = (int64_t)pl->K * pl->D;
+  if (!op) return launch_reduce(pl, pl->partial.d(), sp.nsplit, 4 * KD, B4, st);
+  // one-pass form: 7 slabs per split -- the four fields, then the products u v, u omega, v theta
+  if ((rc = launch_reduce(pl, pl->partial.d(), sp.nsplit, 4 * KD, B4, st, 7 * KD))) return rc;
+  if ((rc = launch_reduce(pl, pl->partial.d() + 4 * KD, sp.nsplit, 3 * KD, pl->Pq.d(), st, 7 * KD))) return rc;
+  pl->op_valid = true;           // csum / Pq now describe these fields (temx_tem_stage2_from_sums)
+  return TEMX_OK;
 }
 
 // ---- large-L (K > 64) second sweep: the fused eddy kernel keeps all coefficients of a d-tile in LDS,
@@ -1719,28 +1763,41 @@ int temx_tem_stage2(temx_plan* pl, const void* ua, const void* va, const void* t
   if (!ua || !va || !ta || !wap || !B4 || !B3) return fail(TEMX_EINVAL, "null argument");
   HIPCHK(hipSetDevice(pl->device));
   hipStream_t st = S_(stream);
-  if (pl->large && pl->lone && pl->op_valid && pl->op_dtype == dtype && pl->op_ptr[0] == ua && pl->op_ptr[1] == va &&
-      pl->op_ptr[2] == ta && pl->op_ptr[3] == wap) {
-    if ((rc = launch_solve(pl, B4, 4, pl->D, pl->C4.d(), pl->zb.d(), st))) return rc;
-    if ((rc = launch_flux_large(pl, pl->C4.d(), st))) return rc;
-    pl->xb_valid = false;          // the native means are not materialised on this path
-    return project_sums<3>(pl, pl->pbuf.d(), 3, 0, B3, st);
-  }
-  if (pl->large) return tem_stage2_large(pl, four(ua, va, ta, wap), dtype, B4, B3, st);
+  if (unfused_stage2(pl)) return tem_stage2_large(pl, four(ua, va, ta, wap), dtype, B4, B3, st);
   // C = G^-1 B4 and the four zonal means ub vb thetab wapb -> zb[0..3]
   if ((rc = launch_solve(pl, B4, 4, pl->D, pl->C4.d(), pl->zb.d(), st))) return rc;
   TimedLaunch tl{};
   time_begin(pl, 1, st, tl);
-  // one-pass class path: the class sums of these very fields are in csum (temx_tem_stage1) -- the
-  // eddy-product sums follow algebraically, the fields are not read again
-  const bool flux = pl->cls && pl->onepass && pl->op_valid && pl->op_dtype == dtype && pl->op_ptr[0] == ua &&
-                    pl->op_ptr[1] == va && pl->op_ptr[2] == ta && pl->op_ptr[3] == wap;
-  rc = flux ? launch_flux_cls(pl, pl->C4.d(), pl->partial.d(), pl->sp_cflux, st)
-            : run_eddy<0>(pl, four(ua, va, ta, wap), dtype, pl->C4.d(), pl->partial.d(), nullptr, st);
+  rc = run_eddy<0>(pl, four(ua, va, ta, wap), dtype, pl->C4.d(), pl->partial.d(), nullptr, st);
   time_end(pl, 1, st, tl);
   if (rc) return rc;
-  return launch_reduce(pl, pl->partial.d(), flux ? pl->sp_cflux.nsplit : eddy_slabs(pl),
-                       (int64_t)3 * pl->K * pl->D, B3, st);
+  return launch_reduce(pl, pl->partial.d(), eddy_slabs(pl), (int64_t)3 * pl->K * pl->D, B3, st);
+}
+
+int temx_tem_stage2_from_sums(temx_plan* pl, const double* B4, double* B3, void* stream) {
+  int rc = tem_ready(pl);
+  if (rc) return rc;
+  if (!B4 || !B3) return fail(TEMX_EINVAL, "null argument");
+  if (!((pl->cls && pl->onepass) || (pl->large && pl->lone)))
+    return fail(TEMX_ESTATE, "the plan does not run the one-pass class path (temx_plan_one_pass)");
+  if (!pl->op_valid)
+    return fail(TEMX_ESTATE, "no class sums: temx_tem_stage1 must precede temx_tem_stage2_from_sums");
+  HIPCHK(hipSetDevice(pl->device));
+  hipStream_t st = S_(stream);
+  if ((rc = launch_solve(pl, B4, 4, pl->D, pl->C4.d(), pl->zb.d(), st))) return rc;
+  if (pl->large) {
+    if ((rc = launch_flux_large(pl, pl->C4.d(), st))) return rc;
+    pl->xb_valid = false;          // the native means are not materialised on this path
+    return project_sums<3>(pl, pl->pbuf.d(), 3, 0, B3, st);
+  }
+  TimedLaunch tl{};
+  time_begin(pl, 1, st, tl);
+  rc = launch_flux_cls(pl, pl->C4.d(), pl->partial.d(), pl->sp_cflux, st);
+  time_end(pl, 1, st, tl);
+  if (rc) return rc;
+  // B3 = (projections of u v, u omega, v theta from sweep 1) + (projected corrections)
+  return launch_reduce(pl, pl->partial.d(), pl->sp_cflux.nsplit, (int64_t)3 * pl->K * pl->D, B3, st, -1,
+                       pl->Pq.d());
 }
 
 int temx_tem_stage3(temx_plan* pl, const double* B3, double* results, double* zonal, void* stream) {
@@ -1769,7 +1826,11 @@ int temx_tem_run(temx_plan* pl, const void* ua, const void* va, const void* ta, 
   int rc = tem_ready(pl);
   if (rc) return rc;
   if ((rc = temx_tem_stage1(pl, ua, va, ta, wap, dtype, pl->B4.d(), stream))) return rc;
-  if ((rc = temx_tem_stage2(pl, ua, va, ta, wap, dtype, pl->B4.d(), pl->B3.d(), stream))) return rc;
+  if (temx_plan_one_pass(pl))
+    rc = temx_tem_stage2_from_sums(pl, pl->B4.d(), pl->B3.d(), stream);
+  else
+    rc = temx_tem_stage2(pl, ua, va, ta, wap, dtype, pl->B4.d(), pl->B3.d(), stream);
+  if (rc) return rc;
   return temx_tem_stage3(pl, pl->B3.d(), results, zonal, stream);
 }
 
@@ -1781,7 +1842,7 @@ int temx_tem_eddy(temx_plan* pl, const void* ua, const void* va, const void* ta,
   HIPCHK(hipSetDevice(pl->device));
   EddyOut eo;
   for (int i = 0; i < TEMX_NEDDY; ++i) eo.p[i] = eddy_ptrs_host[i];
-  if (pl->large) {
+  if (unfused_stage2(pl)) {
     if ((rc = ensure_xb(pl, S_(stream)))) return rc;
     return launch_eddy_from_xbar(pl, four(ua, va, ta, wap), dtype, native_means(pl, 0, 1, 2, 3),
                                  pl->colscale.d(), eo, S_(stream));
@@ -1859,7 +1920,7 @@ int temx_tracer_stage2(temx_plan* pl, const void* q, const void* va, const void*
   const size_t slab = (size_t)pl->K4 * pl->D * 8;
   // coefficients: Ct = (C_q, C_v, C_w); qb -> tz[0]
   if ((rc = launch_solve(pl, Bq, 1, pl->D, pl->Ct.d(), pl->tz.d(), st))) return rc;
-  if (pl->large) {   // q' v' and q' omega' from the native means of the last temx_tem_stage2
+  if (unfused_stage2(pl)) {   // q' v' and q' omega' from the native means of the last temx_tem_stage2
     if ((rc = ensure_xb(pl, st))) return rc;
     const int64_t nd = pl->N * pl->D;
     if ((rc = launch_recon(pl, pl->D, pl->Ct.d(), pl->XB.d() + 4 * nd, st))) return rc;
@@ -1919,9 +1980,11 @@ int temx_tracer_eddy(temx_plan* pl, const void* q, const void* va, const void* w
   eo.p[0] = ptrs3_host[0];
   eo.p[4] = ptrs3_host[1];
   eo.p[5] = ptrs3_host[2];
-  if (pl->large)
+  if (unfused_stage2(pl)) {
+    if (!pl->xb_valid) return fail(TEMX_ESTATE, "temx_tracer_stage2 has not been called since the last TEM run");
     return launch_eddy_from_xbar(pl, four(q, va, va, wap), dtype, native_means(pl, 4, 1, 1, 3), nullptr, eo,
                                  S_(stream));
+  }
   return run_eddy<1>(pl, four(q, va, wap, nullptr), dtype, pl->Ct.d(), nullptr, &eo, S_(stream));
 }
 
@@ -1967,26 +2030,32 @@ int temx_mfma_f64_peak(int device, int iters, double* tflops_out) {
   double* sink = nullptr;
   HIPCHK(hipMalloc(&sink, 8));
   const int blocks = prop.multiProcessorCount * 2;  // 8 waves per CU, 2 per SIMD
-  hipEvent_t a, b;
-  HIPCHK(hipEventCreate(&a));
-  HIPCHK(hipEventCreate(&b));
-  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, iters, sink);  // warm-up
-  HIPCHK(hipEventRecord(a, 0));
-  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, iters, sink);
-  HIPCHK(hipEventRecord(b, 0));
-  HIPCHK(hipEventSynchronize(b));
+  hipEvent_t a = nullptr, b = nullptr;
   float ms = 0.f;
-  HIPCHK(hipEventElapsedTime(&ms, a, b));
+  hipError_t e = hipEventCreate(&a);
+  if (e == hipSuccess) e = hipEventCreate(&b);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, iters, sink);  // warm-up
+    e = hipEventRecord(a, 0);
+  }
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, iters, sink);
+    e = hipEventRecord(b, 0);
+  }
+  if (e == hipSuccess) e = hipEventSynchronize(b);
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+  if (a) (void)hipEventDestroy(a);
+  if (b) (void)hipEventDestroy(b);
+  (void)hipFree(sink);
+  if (e != hipSuccess) return fail(TEMX_EHIP, "mfma peak benchmark failed: %s", hipGetErrorString(e));
   const double flops = (double)blocks * 4.0 * iters * 8.0 * 512.0;
   *tflops_out = flops / (ms * 1e-3) / 1e12;
-  (void)hipEventDestroy(a);
-  (void)hipEventDestroy(b);
-  (void)hipFree(sink);
   return TEMX_OK;
 }
 
 int temx_kernel_timing(temx_plan* pl, int enable) {
   if (!pl) return fail(TEMX_EINVAL, "null plan");
+  HIPCHK(hipSetDevice(pl->device));
   pl->timing = enable != 0;
   for (int w = 0; w < 2; ++w) {
     for (auto& tl : pl->timed[w]) {

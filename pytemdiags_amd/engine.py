@@ -180,6 +180,15 @@ class Plan:
                                        _ptr(B4.contiguous()), _ptr(B3), self._stream()))
         return B3
 
+    def tem_stage2_from_sums(self, B4):
+        """Stage 2 of the one-pass class path (``one_pass``): B3 from the class sums the latest
+        ``tem_stage1`` on this plan stored -- describes the fields that call was given, reads none."""
+        if self.D is None:
+            raise _lib.TemxError(-5, "temx_plan_set_tem has not been called")
+        B3 = torch.empty((3, self.K, self.D), dtype=torch.float64, device=self.device)
+        check(self.lib.temx_tem_stage2_from_sums(self._h, _ptr(B4.contiguous()), _ptr(B3), self._stream()))
+        return B3
+
     def tem_stage3(self, B3, want_zonal=False):
         res, zon = self._alloc_results(want_zonal)
         check(self.lib.temx_tem_stage3(self._h, _ptr(B3.contiguous()), _ptr(res),

@@ -84,7 +84,11 @@ class NcolShardedTEM:
         be = self.backend
         B4 = be.tem_stage1(ua, va, ta, wap)
         allreduce_sum_(B4, self.group)                 # (ii) [4][K][D] zonal sums, one message
-        B3 = be.tem_stage2(ua, va, ta, wap, B4)
+        # one-pass class path: stage 2 works from the class sums stage 1 just stored for these fields
+        if getattr(be, "one_pass", False):
+            B3 = be.tem_stage2_from_sums(B4)
+        else:
+            B3 = be.tem_stage2(ua, va, ta, wap, B4)
         allreduce_sum_(B3, self.group)                 # (iii) [3][K][D] flux sums, one message
         return be.tem_stage3(B3, want_zonal)
 

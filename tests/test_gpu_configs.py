@@ -1,0 +1,114 @@
+"""Every BASELINE.json configuration at its full size, through the C ABI on the GPU.
+
+configs[1] ne30 x 72 x 1 fp64 ............ vs the CPU oracle (exact shape)
+configs[2] ne30 x 72 x 730 time-sharded ... one rank's block, ne30 x 72 x 91, vs the oracle
+configs[3] ne120 x 72 x 30 ............... properties at full size (finite, run-to-run identical bits,
+                                           one-pass == two-pass to 1e-11) + a 2-snapshot sample of
+                                           the same grid vs the oracle on the one-pass path
+configs[4] ne240 x 128 x 1 fp32 .......... vs the oracle (tolerance 2e-5)
+
+Tolerances: fp64 max|d| <= 1e-10 max|ref| per output field; fp32 inputs 2e-5 (the oracle, like the
+reference, rounds eddies and results to fp32).  The inputs are generated on the device
+(temx_synth_fields) and copied to the host for the oracle, so both sides see identical arrays.
+"""
+import numpy as np
+import pytest
+
+from conftest import fieldnorm_err
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _zm_lat():
+    e = np.arange(-90, 91, 1.0)
+    return (e[1:] + e[:-1]) / 2
+
+
+def _vs_oracle(ne, nlev, nt, dtype, tol, force_one_pass=None, monkeypatch=None):
+    from oracle import tem_oracle as orc
+    from pytemdiags_amd import _lib, engine, synth
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test needs a GPU")
+    if force_one_pass is not None and monkeypatch is not None:
+        monkeypatch.setenv("TEMX_ONE_PASS" if force_one_pass else "TEMX_TWO_PASS", "1")
+    lat, lon = synth.cubed_sphere_gll(ne)
+    plev = synth.pressure_levels(nlev)
+    f = engine.synth_fields(0, lat, lon, plev, nt, dtype=dtype, seed=0)
+    plan = engine.Plan(lat, _zm_lat(), 50)
+    plan.set_tem(nlev, nt, plev * 100)
+    res, _ = plan.tem_run(*f)
+    assert not plan.status()
+    one_pass, mode = plan.one_pass, plan.sweep_mode
+    res = res.cpu().numpy()
+    plan.close()
+    host = [x.cpu().numpy() for x in f]
+    del f
+    torch.cuda.empty_cache()
+    ref = orc.TEMOracle(*host, lat, plev, mode="factorised")
+    worst = 0.0
+    for i, n in enumerate(_lib.RESULT_NAMES):
+        r = np.asarray(getattr(ref, n)(), dtype=np.float64)
+        e = fieldnorm_err(res[i], r)
+        worst = max(worst, e)
+        assert e <= tol, (n, e)
+    return worst, one_pass, mode
+
+
+def test_config1_ne30x72x1_f64_vs_oracle():
+    _vs_oracle(30, 72, 1, torch.float64, 1e-10)
+
+
+def test_config2_one_rank_block_ne30x72x91_f64_vs_oracle():
+    worst, one_pass, mode = _vs_oracle(30, 72, 91, torch.float64, 1e-10)
+    import os
+    if not any(os.environ.get(k) == "1" for k in ("TEMX_NO_SYM", "TEMX_NO_CLS", "TEMX_TWO_PASS")):
+        assert mode == 2 and one_pass     # the path bench.py times for this shape
+
+
+def test_config3_sample_ne120x72x2_f64_vs_oracle_on_the_one_pass_path(monkeypatch):
+    """The same grid, levels and code path as the headline workload, 2 of its 30 snapshots."""
+    worst, one_pass, mode = _vs_oracle(120, 72, 2, torch.float64, 1e-10, force_one_pass=True,
+                                       monkeypatch=monkeypatch)
+    import os
+    if not any(os.environ.get(k) == "1" for k in ("TEMX_NO_SYM", "TEMX_NO_CLS", "TEMX_TWO_PASS")):
+        assert one_pass
+
+
+def test_config3_full_size_ne120x72x30_properties(monkeypatch):
+    """Full size (53.7 GB of inputs): no non-finite value, identical bits run to run (fixed-order
+    reductions), and the one-pass and two-pass forms of the class path agree to 1e-11."""
+    from pytemdiags_amd import _lib, engine, synth
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test needs a GPU")
+    lat, lon = synth.cubed_sphere_gll(120)
+    plev = synth.pressure_levels(72)
+    f = engine.synth_fields(0, lat, lon, plev, 30, dtype=torch.float64, seed=0)
+    plan = engine.Plan(lat, _zm_lat(), 50)
+    plan.set_tem(72, 30, plev * 100)
+    r1, _ = plan.tem_run(*f)
+    r1 = r1.clone()
+    r2, _ = plan.tem_run(*f)
+    assert not plan.status()
+    assert torch.isfinite(r1).all()
+    assert torch.equal(r1, r2)
+    one = plan.one_pass
+    plan.close()
+    if one:
+        monkeypatch.setenv("TEMX_TWO_PASS", "1")
+        plan2 = engine.Plan(lat, _zm_lat(), 50)
+        plan2.set_tem(72, 30, plev * 100)
+        assert not plan2.one_pass
+        r3, _ = plan2.tem_run(*f)
+        assert not plan2.status()
+        for i, n in enumerate(_lib.RESULT_NAMES):
+            den = float(r1[i].abs().max())
+            assert float((r3[i] - r1[i]).abs().max()) <= 1e-11 * den, n
+        plan2.close()
+    del f
+    torch.cuda.empty_cache()
+
+
+def test_config4_ne240x128x1_f32_vs_oracle():
+    _vs_oracle(240, 128, 1, torch.float32, 2e-5)

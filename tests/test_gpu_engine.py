@@ -108,7 +108,7 @@ def test_staged_equals_fused_and_nan_flag(eng):
     f = [dev(g[k]) for k in ("ua", "va", "ta", "wap")]
     res, _ = plan.tem_run(*f)
     B4 = plan.tem_stage1(*f)
-    B3 = plan.tem_stage2(*f, B4)
+    B3 = plan.tem_stage2_from_sums(B4) if plan.one_pass else plan.tem_stage2(*f, B4)
     res2, _ = plan.tem_stage3(B3)
     assert torch.equal(res, res2)           # deterministic fixed-order reductions
     res3, _ = plan.tem_run(*f)
@@ -267,4 +267,143 @@ def test_known_answers_over_the_reference_range_of_L(eng, L):
     assert np.max(np.abs(zm[:, 0] - 0.25 * np.sqrt(5 / np.pi) * (3 * np.sin(po) ** 2 - 1))) < 1e-9
     assert np.max(np.abs(zm[:, 1])) < 1e-9 and np.max(np.abs(zm[:, 2])) < 1e-9
     assert np.max(np.abs(zm[:, 3] - (po ** 2 + 1))) < 0.1
+    plan.close()
+
+
+@pytest.mark.parametrize("case", ["opw_gauss24x48_L10", "opw_gauss24x48_L70", "opw_ne4_L10"])
+def test_weights_mode_vs_reference_goldens(eng, case):
+    """`weights` mode against the reference itself called with ``weights=`` (sph_zonal_mean.py:180-181,
+    352-356, 383-386; tools/make_goldens.py weights_case).  The Gaussian grid has latitude classes, so
+    the plan must leave every class path (L = 70: also the large-L one) for the weighted operator."""
+    g = load(case)
+    plan = eng.Plan(g["lat"], g["lat_out"], int(g["L"]), defer_finalize=True)
+    plan.set_weights(g["weights"])
+    assert plan.sweep_mode == 0                  # weighted rows of a latitude do not share a basis row
+    for k in ("y20", "lat2p1", "rand3d", "rand3d_f32"):
+        A = g["in_" + k]
+        tol = TOL32 if A.dtype == np.float32 else TOL64
+        zm = plan.zonal_mean(dev(A)).cpu().numpy()
+        zmn = plan.zonal_mean(dev(A), native=True).cpu().numpy()
+        assert zm.shape == g["zm_" + k].shape and zmn.shape == g["zmn_" + k].shape
+        assert fieldnorm_err(zm, g["zm_" + k]) <= tol, k
+        assert fieldnorm_err(zmn, g["zmn_" + k]) <= tol, k
+    assert not plan.status()
+    plan.close()
+
+
+@pytest.mark.parametrize("L", [30, 100])
+def test_weights_mode_tem_pipeline_on_a_class_grid(eng, L):
+    """set_weights, then the TEM pipeline, on a grid with latitude classes (L = 100: the large-L class
+    path must be off as well): the weights must reach every zonal mean of the pipeline."""
+    from oracle import tem_oracle as orc
+    from pytemdiags_amd import _lib, synth
+    nlat, nlon, nlev, nt = 64, 16, 9, 8
+    xg, wg = np.polynomial.legendre.leggauss(nlat)
+    lat = np.repeat(np.rad2deg(np.arcsin(xg)), nlon)
+    lon = np.tile(np.arange(nlon) * (360.0 / nlon), nlat)
+    w = np.repeat(wg / (2.0 * nlon), nlon)
+    plev = synth.pressure_levels(nlev)
+    f = synth.analytic_fields(lat, lon, plev, nt, seed=4)
+    ref = orc.TEMOracle(*f, lat, plev, L=L, zm_dlat=3, weights=w.copy())
+    plan = eng.Plan(lat, ref.lat, L, defer_finalize=True)
+    plan.set_weights(w)
+    plan.set_tem(nlev, nt, plev * 100)
+    assert plan.sweep_mode == 0 and not plan.one_pass
+    res, zon = plan.tem_run(*[dev(x) for x in f], want_zonal=True)
+    assert not plan.status()
+    for i, n in enumerate(_lib.ZONAL_NAMES[:7]):
+        e = fieldnorm_err(zon[i].cpu().numpy(), getattr(ref, n))
+        assert e <= TOL64, (n, e)
+    for i, n in enumerate(_lib.RESULT_NAMES):
+        e = fieldnorm_err(res[i].cpu().numpy(), getattr(ref, n)())
+        assert e <= 1e-9, (n, e)      # psi = vptpb / dthetab_dp amplifies on this coarse 64 x 16 grid
+    plan.close()
+
+
+def test_stage_contract_fields_changed_between_the_stages(eng, monkeypatch):
+    """temx_tem_stage2 always reads the fields it is given; temx_tem_stage2_from_sums describes the
+    fields of the latest temx_tem_stage1.  Mutating a field in place between the stages, or handing
+    over non-contiguous views (the wrapper makes temporaries whose addresses the caching allocator
+    recycles), must give the answer for the data that was passed -- never stale class sums."""
+    from oracle import tem_oracle as orc
+    from pytemdiags_amd import _lib, synth
+    monkeypatch.setenv("TEMX_ONE_PASS", "1")
+    lat, lon = synth.cubed_sphere_gll(6)
+    plev = synth.pressure_levels(16)
+    nt = 4
+    fa = synth.analytic_fields(lat, lon, plev, nt, seed=1)
+    fb = synth.analytic_fields(lat, lon, plev, nt, seed=2)
+    plan = eng.Plan(lat, np.linspace(-88.5, 88.5, 60), 50)
+    plan.set_tem(16, nt, plev * 100)
+
+    def check(res, f, tag):
+        ref = orc.TEMOracle(*f, lat, plev, zm_dlat=3, mode="factorised")
+        for i, n in enumerate(_lib.RESULT_NAMES):
+            e = fieldnorm_err(res[i].cpu().numpy(), getattr(ref, n)())
+            assert e <= TOL64, (tag, n, e)
+
+    # (1) in-place update of ua between the stages: stage 2 with fields sees the new data
+    d = [dev(x) for x in fa]
+    plan.tem_stage1(*d)                                  # class sums of fa now sit in the plan
+    d[0].copy_(dev(fb[0]))
+    mixed = [fb[0], fa[1], fa[2], fa[3]]
+    B4 = plan.tem_stage1(*d)
+    d[1].copy_(dev(fb[1]))                               # ... and again after the second stage 1
+    mixed2 = [fb[0], fb[1], fa[2], fa[3]]
+    B4 = plan.tem_stage1(*d)
+    B3 = plan.tem_stage2(*d, B4)
+    check(plan.tem_stage3(B3)[0], mixed2, "in-place")
+    # stage 1 on fa, then the whole pipeline for other data through stage 2 with fields
+    plan.tem_stage1(*[dev(x) for x in fa])
+    db = [dev(x) for x in fb]
+    B4b = plan.tem_stage1(*db)
+    plan.tem_stage1(*[dev(x) for x in fa])               # stale sums (of fa) in the plan
+    B3b = plan.tem_stage2(*db, B4b)                      # must ignore them
+    check(plan.tem_stage3(B3b)[0], fb, "stale sums")
+    # (2) non-contiguous inputs: [ncol][nt][nlev] storage viewed as [ncol][nlev][nt]
+    nc = [dev(np.ascontiguousarray(x.transpose(0, 2, 1))).transpose(1, 2) for x in fb]
+    assert not nc[0].is_contiguous()
+    res, _ = plan.tem_run(*[dev(x) for x in fa])         # leaves fa's sums behind
+    B4n = plan.tem_stage1(*nc)
+    B3n = plan.tem_stage2(*nc, B4n)
+    check(plan.tem_stage3(B3n)[0], fb, "non-contiguous, stage 2 with fields")
+    res, _ = plan.tem_run(*nc)
+    check(res, fb, "non-contiguous, tem_run")
+    # (3) from_sums is explicit about what it describes, and refuses when there is nothing to describe
+    if plan.one_pass:
+        B4 = plan.tem_stage1(*db)
+        check(plan.tem_stage3(plan.tem_stage2_from_sums(B4))[0], fb, "from sums")
+        plan.set_tem(16, nt, plev * 100)                 # reconfiguring voids the sums
+        with pytest.raises(_lib.TemxError):
+            plan.tem_stage2_from_sums(B4)
+    assert not plan.status()
+    plan.close()
+
+
+@pytest.mark.parametrize("jitter_deg, classes_stay", [(5e-13, True), (1e-9, False)])
+def test_latitudes_jittered_around_the_class_tolerance(eng, jitter_deg, classes_stay):
+    """Columns share a latitude class when their |lat| agree to 1e-12 degrees.  Jitter inside that
+    tolerance keeps the class path and parity (<= 1e-10 against the oracle ON THE JITTERED
+    latitudes); jitter outside it must drop to another sweep form, parity unchanged."""
+    from oracle import tem_oracle as orc
+    from pytemdiags_amd import _lib, synth
+    lat, lon = synth.cubed_sphere_gll(16)
+    rng = np.random.default_rng(16)
+    latj = lat + rng.uniform(-jitter_deg, jitter_deg, lat.size)
+    plev = synth.pressure_levels(12)
+    f = synth.analytic_fields(lat, lon, plev, 2, seed=16)
+    ref = orc.TEMOracle(*f, latj, plev, mode="factorised")
+    plan = eng.Plan(latj, ref.lat, 50)
+    plan.set_tem(12, 2, plev * 100)
+    structured = not any(os.environ.get(k) == "1" for k in ("TEMX_NO_SYM", "TEMX_NO_CLS"))
+    if structured:
+        assert (plan.sweep_mode == 2) == classes_stay, plan.sweep_mode
+    res, zon = plan.tem_run(*[dev(x) for x in f], want_zonal=True)
+    assert not plan.status()
+    for i, n in enumerate(_lib.RESULT_NAMES):
+        e = fieldnorm_err(res[i].cpu().numpy(), getattr(ref, n)())
+        assert e <= TOL64, (n, e)
+    for i, n in enumerate(_lib.ZONAL_NAMES):
+        e = fieldnorm_err(zon[i].cpu().numpy(), getattr(ref, n))
+        assert e <= TOL64, (n, e)
     plan.close()

@@ -83,10 +83,16 @@ def test_two_ranks_on_one_gpu(mode):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, ret)) for r in range(2)]
     for p in procs:
         p.start()
-    got, paired, bad = ret.get(timeout=300)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    try:
+        got, paired, bad = ret.get(timeout=300)
+    finally:      # a crashed rank must not leave its sibling running (and holding the GPU)
+        for p in procs:
+            p.join(timeout=120)
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=30)
+    assert [p.exitcode for p in procs] == [0, 0]
     assert paired == (os.environ.get("TEMX_NO_SYM") != "1") and not bad
     # unsharded reference run in this process
     plan = engine.Plan(lat, lat_zm, 50)

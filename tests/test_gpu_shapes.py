@@ -208,7 +208,8 @@ def test_ncol_sharded_flow_emulated_on_one_gpu(symmetric_shards):
         idx = torch.as_tensor(p, device="cuda:0")
         loc.append([x[idx].contiguous() for x in f] + [q[idx].contiguous()])
     B4 = sum(pl.tem_stage1(*l[:4]) for pl, l in zip(plans, loc))        # all-reduce (ii)
-    B3 = sum(pl.tem_stage2(*l[:4], B4) for pl, l in zip(plans, loc))    # all-reduce (iii)
+    B3 = sum(pl.tem_stage2_from_sums(B4) if pl.one_pass else pl.tem_stage2(*l[:4], B4)
+             for pl, l in zip(plans, loc))                              # all-reduce (iii)
     for pl in plans:                                                    # every rank: same epilogue
         res, _ = pl.tem_stage3(B3)
         for i, n in enumerate(_lib.RESULT_NAMES):
@@ -409,10 +410,10 @@ def test_one_pass_class_path_vs_oracle(ne, nlev, nt, dtype, L, force_one_pass):
     for i, n in enumerate(_lib.ZONAL_NAMES):
         e = fieldnorm_err(zon[i].cpu().numpy(), getattr(ref, n))
         assert e <= tol, (n, e)
-    # staged == fused; stage 2 on *copies* of the fields cannot use the stored class sums and falls
-    # back to the two-pass sweep: same numbers up to rounding
+    # staged == fused; stage 2 given fields always re-reads them (two-pass sweep): same numbers up
+    # to rounding
     B4 = plan.tem_stage1(*d)
-    B3 = plan.tem_stage2(*d, B4)
+    B3 = plan.tem_stage2_from_sums(B4) if plan.one_pass else plan.tem_stage2(*d, B4)
     res2, _ = plan.tem_stage3(B3)
     assert torch.equal(res, res2)
     d2 = [x.clone() for x in d]

@@ -69,6 +69,24 @@ def test_operator_goldens(mode):
         assert np.max(np.abs(zmn.astype(float) - g["zmn_" + k])) <= tol * den, k
 
 
+@pytest.mark.parametrize("case", ["opw_gauss24x48_L10", "opw_gauss24x48_L70", "opw_ne4_L10"])
+def test_weights_mode_goldens(case):
+    """`weights` mode, Y0inv = Y0^T diag(4 pi w) (sph_zonal_mean.py:180-181, 383-386): the oracle's
+    weights branch against the reference called with ``weights=``."""
+    g = load(case)
+    Z = orc.ZonalAverager(g["lat"], g["lat_out"], int(g["L"]), weights=g["weights"])
+    for k in ("y20", "lat2p1", "rand3d", "rand3d_f32"):
+        A = g["in_" + k]
+        tol = 1e-5 if A.dtype == np.float32 else 1e-12
+        zm, zmn = Z.zonal_mean(A), Z.zonal_mean_native(A)
+        assert zm.dtype == A.dtype and zmn.dtype == A.dtype
+        assert fieldnorm_err(zm, g["zm_" + k]) <= tol, k
+        assert fieldnorm_err(zmn, g["zmn_" + k]) <= tol, k
+    np.testing.assert_allclose(Z.Y0inv @ Z.Y0, g["Y0inv_Y0"], rtol=0, atol=1e-12)
+    if case == "opw_gauss24x48_L10":      # exact quadrature weights: Y0^T diag(4 pi w) Y0 = I
+        assert np.max(np.abs(g["Y0inv_Y0"] - np.eye(11))) < 1e-13
+
+
 def test_reference_known_answers():
     """tests_sph_zonal_mean.py:465-475: zm(Y_2^0) = Y_2^0(lat_out); zm(lat^2+1) ~ f(lat_out)."""
     g = load("op_ne4_L30")

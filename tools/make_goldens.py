@@ -103,6 +103,45 @@ def operator_case(name, ne, L):
     print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6))
 
 
+def weights_case(name, L, nlat=24, nlon=48, ne=None):
+    """The operator in `weights` mode, Y0inv = Y0^T diag(4 pi w) (sph_zonal_mean.py:180-181, 352-356,
+    383-386): the reference called with ``weights=``.  Grid: a Gaussian lat-lon grid with its exact
+    quadrature weights (Gauss-Legendre weight / (2 nlon), summing to 1), or -- ``ne`` given -- the
+    cubed-sphere test grid with the crude equal-area guess 1/N."""
+    if ne is None:
+        xg, wg = np.polynomial.legendre.leggauss(nlat)
+        lat = np.repeat(np.rad2deg(np.arcsin(xg)), nlon)
+        lon = np.tile(np.arange(nlon) * (360.0 / nlon), nlat)
+        w = np.repeat(wg / (2.0 * nlon), nlon)
+    else:
+        lat, lon = synth.cubed_sphere_gll(ne)
+        w = np.full(lat.size, 1.0 / lat.size)
+    lat_out = (np.arange(-90, 90 + 3.0, 3.0)[1:] + np.arange(-90, 90 + 3.0, 3.0)[:-1]) / 2
+    # the reference scales its weights argument in place (sph_zonal_mean.py:181): hand it a copy
+    ZM = PyTEMDiags.sph_zonal_averager(lat, lat_out, L, weights=w.copy(), debug=False, save_dest="/nonexistent")
+    ZM.sph_compute_matrices(no_write=True)
+    rng = np.random.default_rng(11)
+    colat = np.deg2rad(90 - lat)
+    from scipy.special import sph_harm
+    fields = {
+        "y20": sph_harm(0, 2, np.deg2rad(lon), colat).real,
+        "lat2p1": np.deg2rad(lat) ** 2 + 1,
+        "rand3d": rng.standard_normal((lat.size, 5, 4)),
+        "rand3d_f32": rng.standard_normal((lat.size, 3, 2)).astype(np.float32),
+    }
+    out = dict(lat=lat, lon=lon, lat_out=lat_out, L=np.int64(L), weights=w, Y0inv_Y0=ZM.Y0inv @ ZM.Y0)
+    for k, v in fields.items():
+        dims = ("ncol",) + tuple("d%d" % i for i in range(v.ndim - 1))
+        A = xr.DataArray(v, dims=dims)
+        out["in_" + k] = v
+        out["zm_" + k] = ZM.sph_zonal_mean(A).values
+        out["zmn_" + k] = ZM.sph_zonal_mean_native(A).values
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6),
+          "max|Y0inv Y0 - I| = %.2e" % np.max(np.abs(out["Y0inv_Y0"] - np.eye(L + 1))))
+
+
 def tracer_case(name, ne, nlev, nt, qdtypes=(np.float64, np.float64), dtype=np.float64, seed=2):
     """TEM with tracers (tem_diagnostics.py:281-301, 532-538, 560-570, 602-611, 801-991)."""
     TRES = ("etfy", "etfz", "etdiv", "qtendetfd", "qtendvtem", "qtendwtem")
@@ -149,6 +188,10 @@ if __name__ == "__main__":
         # D = 64 = one quad of d-tiles: the smallest shape the one-pass class path takes
         (tem_case, ("tem_ne4_16x4_f64", 4, 16, 4), dict(keep_native=False, seed=7)),
         (operator_case, ("op_ne4_L30", 4, 30), {}),
+        # weights mode (sph_zonal_mean.py:180-181, 383-386); L = 70 exercises the K > 64 paths
+        (weights_case, ("opw_gauss24x48_L10", 10), {}),
+        (weights_case, ("opw_gauss24x48_L70", 70), {}),
+        (weights_case, ("opw_ne4_L10", 10), dict(ne=4)),
         (tracer_case, ("tracer_ne4_10x2_f64", 4, 10, 2), {}),
         (tracer_case, ("tracer_ne4_10x2_qf32", 4, 10, 2), dict(qdtypes=(np.float32,))),
     ]
