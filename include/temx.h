@@ -212,6 +212,14 @@ int temx_tracer_stage1(temx_plan* plan, const void* q, int dtype, double* Bq, vo
 int temx_tracer_stage2(temx_plan* plan, const void* q, const void* va, const void* wap, int dtype,
                        const double* Bq, double* Bq2, void* stream);
 int temx_tracer_stage3(temx_plan* plan, const double* Bq2, double* tres, double* tzon, void* stream);
+/* One-pass form of stages 1 and 2 (temx_plan_one_pass(plan) == 1 and the plan holds the class sums of a
+ * temx_tem_stage1 / temx_tem_run on the SAME va, wap): stage1_sums reads (q, v, omega) once -- raw sums
+ * Bq, and per latitude class the sum of q and the centred co-moments of q v, q omega; stage2_from_sums
+ * forms Bq2 from those and the TEM run's class sums of v and omega without reading a field.
+ * TEMX_ESTATE when the plan is not in that state; temx_tracer_run uses this form whenever it can. */
+int temx_tracer_stage1_sums(temx_plan* plan, const void* q, const void* va, const void* wap, int dtype,
+                            double* Bq, void* stream);
+int temx_tracer_stage2_from_sums(temx_plan* plan, const double* Bq, double* Bq2, void* stream);
 int temx_tracer_run(temx_plan* plan, const void* q, const void* va, const void* wap, int dtype,
                     double* tres, double* tzon, void* stream);
 /* lazily materialise qp, qpvp, qpwapp ([ncol][D] fp64 each; NULL entries skipped) of the tracer

@@ -384,7 +384,8 @@ constexpr int SOLVE_MB = 16;          // 4-row blocks of output latitudes per z-
 template <int TB>
 __global__ void __launch_bounds__(256)
 solve_mfma_kernel(const double* __restrict__ B, int K, int M, int64_t D, const double* __restrict__ gblk,
-                  const double* __restrict__ ypblk, double* __restrict__ C, double* __restrict__ Xb) {
+                  const double* __restrict__ ypblk, double* __restrict__ C, double* __restrict__ Xb,
+                  int mbs /* 4-row blocks of output latitudes per z-slice, <= SOLVE_MB */) {
   extern __shared__ double slds[];          // sg[TB*TB*16], sy[SOLVE_MB*TB*16]
   double* sg = slds;
   double* sy = slds + TB * TB * 16;
@@ -394,9 +395,9 @@ solve_mfma_kernel(const double* __restrict__ B, int K, int M, int64_t D, const d
   const int64_t d = ((int64_t)blockIdx.x * 4 + wave) * 16 + c;
   const bool dvalid = d < D;
   const int64_t dcl = dvalid ? d : D - 1;
-  const int mb0 = blockIdx.z * SOLVE_MB;
+  const int mb0 = blockIdx.z * mbs;
   const int nmb_all = (M + 3) >> 2;
-  const int nmb = Xb != nullptr ? (nmb_all - mb0 < SOLVE_MB ? nmb_all - mb0 : SOLVE_MB) : 0;
+  const int nmb = Xb != nullptr ? (nmb_all - mb0 < mbs ? nmb_all - mb0 : mbs) : 0;
 
   double breg[TB];
 #pragma unroll
@@ -767,8 +768,12 @@ pint_scan_kernel(const double* __restrict__ vb, const double* __restrict__ p, in
 // One thread per zonal grid point; every stencil is recomputed from the seven zonal means
 // (all L1/L2 resident), so the ten GM16 Table-A1 outputs come out of a single launch.
 // zb: [8][M][D] = ub vb thetab wapb upvpb upwappb vptpb int_vbdp.
+// INLINE_INT: int_vbdp (the cumulative trapezoid of vb from the model top, tem_util.py:230-232) is summed
+// by the thread itself -- O(nlev) L1/L2 reads per point, one launch fewer than pint_scan_kernel (it is the
+// launches, 4-8 us each, that small shapes pay for) -- and stored to zb[7] for later readers.
+template <bool INLINE_INT>
 __global__ void __launch_bounds__(256)
-tem_epilogue_kernel(const double* __restrict__ zb, int M, int nlev, int64_t nt, EpiTables tb,
+tem_epilogue_kernel(double* __restrict__ zb, int M, int nlev, int64_t nt, EpiTables tb,
                     double p0, double* __restrict__ res, double* __restrict__ zon) {
   // constants.py:6-14 (NB: pi is the reference's truncated value, used by psitem only)
   constexpr double a_e = 6.37123e6, g0 = 9.80665, Hs = 7000.0, pi_ref = 3.14159;
@@ -787,11 +792,27 @@ tem_epilogue_kernel(const double* __restrict__ zb, int M, int nlev, int64_t nt, 
   const double* upvpb = zb + 4 * MD;
   const double* upwb = zb + 5 * MD;
   const double* vptpb = zb + 6 * MD;
-  const double* intv = zb + 7 * MD;
 
   auto at = [&](const double* A, int mm, int jj) { return A[((int64_t)mm * nlev + jj) * nt + t]; };
   auto clj = [&](int jj) { return jj < 0 ? 0 : (jj >= nlev ? nlev - 1 : jj); };
   auto clm = [&](int mm) { return mm < 0 ? 0 : (mm >= M ? M - 1 : mm); };
+  double intv0;                              // int_vbdp at (m, j)
+  if constexpr (INLINE_INT) {
+    double a0 = 0.0, a1 = 0.0;               // two chains: the adds are the critical path
+    double vprev = at(vb, m, 0);
+    int jj = 1;
+    for (; jj + 1 <= j; jj += 2) {
+      const double v1 = at(vb, m, jj), v2 = at(vb, m, jj + 1);
+      a0 += (tb.p[jj] - tb.p[jj - 1]) * (v1 + vprev) / 2.0;
+      a1 += (tb.p[jj + 1] - tb.p[jj]) * (v2 + v1) / 2.0;
+      vprev = v2;
+    }
+    if (jj <= j) a0 += (tb.p[jj] - tb.p[jj - 1]) * (at(vb, m, jj) + vprev) / 2.0;
+    intv0 = a0 + a1;
+    zb[7 * MD + idx] = intv0;
+  } else {
+    intv0 = zb[7 * MD + idx];
+  }
   // d/dp with numpy's second-order non-uniform interior, first-order edges (tem_util.py:192)
   auto ddp = [&](const double* A, int mm, int jj) {
     return tb.pg[jj * 3 + 0] * at(A, mm, clj(jj - 1)) + tb.pg[jj * 3 + 1] * at(A, mm, jj) +
@@ -832,7 +853,7 @@ tem_epilogue_kernel(const double* __restrict__ zb, int M, int nlev, int64_t nt, 
   const double vtem = at(vb, m, j) - dpsi_dp;                                    // :622
   const double omegatem = at(wb, m, j) + dpsicos_dlat * inv_acos;                // :639
   const double wtem = omegatem * (-Hs / tb.p[j]);                                // :657
-  const double psitem = 2 * pi_ref * a_e / g0 * ((at(intv, m, j) - psi0) * cosm);  // :674
+  const double psitem = 2 * pi_ref * a_e / g0 * ((intv0 - psi0) * cosm);           // :674
   const double epfy = epfy_at(m, j, psi0);
   const double epfz = epfz_at(m, j, psi0);
   // EP flux divergence (tem_diagnostics.py:730-736)
@@ -871,7 +892,7 @@ tem_epilogue_kernel(const double* __restrict__ zb, int M, int nlev, int64_t nt, 
     zon[12 * MD + idx] = psicos;
     zon[13 * MD + idx] = dpsicos_dlat;
     zon[14 * MD + idx] = dpsi_dp;
-    zon[15 * MD + idx] = at(intv, m, j);
+    zon[15 * MD + idx] = intv0;
   }
 }
 

@@ -104,13 +104,11 @@ __global__ void cls_basis_kernel(const double* __restrict__ xc, int64_t ncls, in
 // PD = X batches held in registers (PD - 1 in flight while one is consumed); the small one-field-
 // per-wave configuration has the registers for a deeper ring, which is what short batch lists
 // (small D) need: they are latency, not bandwidth, bound.
-// OP ("one pass", NF = NFW = 4 only): the sweep also accumulates, per class and side, the sums of u v,
-// u omega and v T next to the four field sums, projects them like the fields (partial holds NF + 3
-// slabs per split) and stores the 4 x 2 field sums of every (class-group, d-tile) in csum: with them
-// flux_cls_kernel gets the eddy-product sums of a class algebraically (x-bar is constant inside a
-// class side), so the fields are read ONCE.  Needs work cuts at group boundaries.
-// PROJ = false (with OP): only the class sums are produced -- the sliced large-L class path projects
-// them afterwards, 64 harmonics at a time (sums_project_kernel).
+// OP with PROJ = false (NF = NFW = 4 only; the large-L class path, 64 < K <= 256): no projection, the
+// sweep only accumulates, per class and side, the four field sums and the sums of u v, u omega, v T and
+// stores the 7 x 2 sums of every (class-group, d-tile) in csum; sums_project_kernel and
+// flux_large_kernel work on them 64 harmonics at a time.  Needs work cuts at group boundaries.
+// (The one-pass form for K <= 64, which projects while it sums, is sweep_op_kernel in kernels_op.hpp.)
 template <typename T, int NF, int NFW, int TBS, int WPS, int PD, bool OP, bool PROJ = true>
 __global__ void __launch_bounds__(256, WPS)
 project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict__ ycls,
@@ -118,7 +116,7 @@ project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
                    const double* __restrict__ colscale, int sfield, double* __restrict__ partial, int nsplit,
                    int ndt, double* __restrict__ csum) {
   static_assert(!OP || (NF == 4 && NFW == 4), "one-pass sums need all four fields in one wave");
-  static_assert(PROJ || OP, "a sweep must produce something");
+  static_assert(PROJ != OP, "either the projections or the class sums (sweep_op_kernel produces both)");
   constexpr int DPW = 4 * NFW / NF;
   constexpr int NB = 2 * TBS;
   constexpr int YE = NB * 16;
@@ -160,14 +158,6 @@ project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
 #pragma unroll
   for (int f = 0; f < NFW; ++f) sN[f] = sS[f] = 0.0;
   double qN[3] = {0.0, 0.0, 0.0}, qS[3] = {0.0, 0.0, 0.0};   // OP: sums of u v, u omega, v T
-  // CEN (the one-pass form that projects): the sums of a class side are accumulated about the side's
-  // first member x0 -- S~ = sum (x - x0), q~ = sum (u - u0)(v - v0) -- and turned into the true sums
-  // S = S~ + n x0 and the CENTRED co-moments  C_uv = sum (u - m_u)(v - m_v) = q~ - S~_u S~_v / n
-  // (m = S / n) when the class-group is complete.  Unlike S_uv = sum u v, whose eddy part sits under
-  // n ub vb (v theta: a factor 1e4), the co-moments carry no large cancelling term.
-  constexpr bool CEN = OP && PROJ;
-  double x0N[4] = {0.0, 0.0, 0.0, 0.0}, x0S[4] = {0.0, 0.0, 0.0, 0.0}, cntN = 0.0, cntS = 0.0;
-  bool side_open_N = false, side_open_S = false;             // uniform: a batch of that side has been seen
 
   T xb[PD][MB][NFW];
   int er[PD][MB];
@@ -200,33 +190,7 @@ project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
     double wt[MB];                            // padding entries read row 0 and weigh nothing
 #pragma unroll
     for (int j = 0; j < MB; ++j) wt[j] = er[P][j] < 0 ? 0.0 : 1.0;
-    if constexpr (CEN) {
-      const bool south = (flags & CLS_SOUTH) != 0;
-      double* sx = south ? sS : sN;
-      double* sq = south ? qS : qN;
-      double* x0 = south ? x0S : x0N;
-      double& cnt = south ? cntS : cntN;
-      bool& open = south ? side_open_S : side_open_N;
-      if (!open) {                            // first batch of this side: its first member is the origin
-        open = true;                          // (a padding entry reads row 0: any origin is valid)
-#pragma unroll
-        for (int f = 0; f < 4; ++f) x0[f] = (double)xb[P][0][f];
-      }
-#pragma unroll
-      for (int j = 0; j < MB; ++j) {
-        const double du = (double)xb[P][j][0] - x0[0], dv = (double)xb[P][j][1] - x0[1];
-        const double dt_ = (double)xb[P][j][2] - x0[2], dw = (double)xb[P][j][3] - x0[3];
-        const double u = wt[j] * du, v = wt[j] * dv;
-        sx[0] += u;
-        sx[1] += v;
-        sx[2] += wt[j] * dt_;
-        sx[3] += wt[j] * dw;
-        sq[0] += u * dv;
-        sq[1] += u * dw;
-        sq[2] += v * dt_;
-        cnt += wt[j];
-      }
-    } else if constexpr (OP) {
+    if constexpr (OP) {
       double* sx = (flags & CLS_SOUTH) ? sS : sN;
       double* sq = (flags & CLS_SOUTH) ? qS : qN;
 #pragma unroll
@@ -257,19 +221,6 @@ project_cls_kernel(FieldPtrs<NF> fp, int64_t D, int K, const double* __restrict_
 #pragma unroll
         for (int j = 0; j < YJ; ++j)
           if (lane + 64 * j < YE) yst[lane + 64 * j] = ys[j];
-      }
-      if constexpr (CEN) {                    // shifted sums -> centred co-moments and true sums
-        const double rN = cntN > 0.0 ? 1.0 / cntN : 0.0, rS = cntS > 0.0 ? 1.0 / cntS : 0.0;
-        qN[0] -= sN[0] * sN[1] * rN;  qS[0] -= sS[0] * sS[1] * rS;     // u v
-        qN[1] -= sN[0] * sN[3] * rN;  qS[1] -= sS[0] * sS[3] * rS;     // u omega
-        qN[2] -= sN[1] * sN[2] * rN;  qS[2] -= sS[1] * sS[2] * rS;     // v T
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          sN[f] += cntN * x0N[f];
-          sS[f] += cntS * x0S[f];
-        }
-        cntN = cntS = 0.0;
-        side_open_N = side_open_S = false;
       }
       if constexpr (OP) {                     // RS sums per side of this (group, d-tile), theta-scaled
         if (dvalid) {
@@ -594,17 +545,19 @@ eddy_cls_kernel(FieldPtrs<4> fp, int64_t D, int K, int K4, const double* __restr
 // d-tile) instead of the fields; the caller adds the co-moment projections of sweep 1 (launch_reduce
 // with an addend).  No term is a difference of large numbers.
 // ------------------------------------------------------------------------------------------------
-template <int TBS, int DPW>
+// KIND 1 (tracer): fields (q, v, omega) -- the sums of q come from csq (records of one pair), those of v and
+// omega from rows 1 and 3 of the TEM run's csum; products q'v', q'omega'.
+template <int TBS, int DPW, int KIND = 0>
 __global__ void __launch_bounds__(512, 2)
 flux_cls_kernel(int64_t D, int K, int K4, const double* __restrict__ ycls, const double* __restrict__ csum,
-                const double* __restrict__ ccnt, int64_t ngroups, const double* __restrict__ C,
-                double* __restrict__ partial, int nsplit, int ndt) {
+                const double* __restrict__ csq, const double* __restrict__ ccnt, int64_t ngroups,
+                const double* __restrict__ C, double* __restrict__ partial, int nsplit, int ndt) {
   extern __shared__ double lds[];
   constexpr int NB = 2 * TBS;
   constexpr int YE = NB * 16;
   constexpr int YJ = (YE + 63) / 64;
   constexpr int NP = 8 / DPW;
-  constexpr int NFR = 4, NPR = 3;
+  constexpr int NFR = KIND == 0 ? 4 : 3, NPR = KIND == 0 ? 3 : 2;
   int split, dq;
   if (!wg_work((ndt + DPW - 1) / DPW, nsplit, split, dq)) return;
   const int wave = uniform_wave(), lane = threadIdx.x & 63;
@@ -644,7 +597,7 @@ flux_cls_kernel(int64_t D, int K, int K4, const double* __restrict__ ycls, const
 #pragma unroll
     for (int t = 0; t < NB; ++t) acc[q][t] = 0.0;
 
-  double sv[2][8], cn[2][2], ys[2][YJ];
+  double sv[2][2 * NFR], cn[2][2], ys[2][YJ];
   auto load = [&](auto pc, int gi) __attribute__((always_inline)) {
     constexpr int P = decltype(pc)::value;
     const double2* base = reinterpret_cast<const double2*>(csum + (((int64_t)gi * ndt + (active ? dt : 0)) * 8) * 64) + lane;
@@ -653,10 +606,16 @@ flux_cls_kernel(int64_t D, int K, int K4, const double* __restrict__ ycls, const
     cn[P][0] = ccnt[(int64_t)gi * 8 + g];
     cn[P][1] = ccnt[(int64_t)gi * 8 + 4 + g];
 #pragma unroll
-    for (int s_ = 0; s_ < 4; ++s_) {
-      const double2 v2 = base[s_ * 64];
+    for (int s_ = 0; s_ < NFR; ++s_) {
+      double2 v2;
+      if (KIND == 0)
+        v2 = base[s_ * 64];
+      else if (s_ == 0)           // q: its own records of one {north, south} pair
+        v2 = (reinterpret_cast<const double2*>(csq + (((int64_t)gi * ndt + (active ? dt : 0)) * 2) * 64) + lane)[0];
+      else                        // v, omega: rows 1 and 3 of the TEM record
+        v2 = base[(s_ == 1 ? 1 : 3) * 64];
       sv[P][s_] = v2.x;           // northern members
-      sv[P][4 + s_] = v2.y;       // southern members
+      sv[P][NFR + s_] = v2.y;     // southern members
     }
   };
   auto step = [&](auto pc, int gi) __attribute__((always_inline)) {
@@ -684,16 +643,20 @@ flux_cls_kernel(int64_t D, int K, int K4, const double* __restrict__ ycls, const
     double pr[2][NPR];
 #pragma unroll
     for (int sd = 0; sd < 2; ++sd) {
-      const double* S = sv[P] + 4 * sd;
+      const double* S = sv[P] + NFR * sd;
       const double n = cn[P][sd], rn = n > 0.0 ? 1.0 / n : 0.0;
       // class-side mean minus the zonal mean at the class latitude (E + O north, E - O south)
-      const double du = S[0] * rn - (sd ? E[0] - O[0] : E[0] + O[0]);
-      const double dv = S[1] * rn - (sd ? E[1] - O[1] : E[1] + O[1]);
-      const double dth = S[2] * rn - (sd ? E[2] - O[2] : E[2] + O[2]);
-      const double dw = S[3] * rn - (sd ? E[3] - O[3] : E[3] + O[3]);
-      pr[sd][0] = n * du * dv;       // sum u'v'     - C_uv
-      pr[sd][1] = n * du * dw;       // sum u'omega' - C_uw
-      pr[sd][2] = n * dv * dth;      // sum v'theta' - C_vtheta
+      double dl[NFR];
+#pragma unroll
+      for (int f = 0; f < NFR; ++f) dl[f] = S[f] * rn - (sd ? E[f] - O[f] : E[f] + O[f]);
+      if (KIND == 0) {
+        pr[sd][0] = n * dl[0] * dl[1];             // sum u'v'     - C_uv
+        pr[sd][1] = n * dl[0] * dl[NFR - 1];       // sum u'omega' - C_uw
+        pr[sd][NPR - 1] = n * dl[1] * dl[2];       // sum v'theta' - C_vtheta
+      } else {
+        pr[sd][0] = n * dl[0] * dl[1];             // sum q'v'     - C_qv
+        pr[sd][1] = n * dl[0] * dl[2];             // sum q'omega' - C_qw
+      }
     }
 #pragma unroll
     for (int tb = 0; tb < NB; ++tb) {

@@ -18,6 +18,7 @@
 #include "kernels.hpp"
 #include "kernels_sym.hpp"
 #include "kernels_cls.hpp"
+#include "kernels_op.hpp"
 
 using namespace temx;
 
@@ -115,6 +116,8 @@ struct temx_plan {
   int64_t cgroups = 0, cbatches = 0, ncls = 0;
   std::vector<int> gbatch0;            // first batch of every class-group (+ total)
   DevBuf crow, ycls;
+  std::vector<int> crow_host;          // the row table as built (temx_plan_set_tem derives coff from it)
+  DevBuf coff;                         // one-pass sweep 1: 64-bit element offsets row * D + batch flags (kernels_op.hpp)
   std::map<int, DevBuf> csplits;       // work cuts per number of pieces
   Split sp_cproj4, sp_cproj1, sp_ceddy, sp_cflux;
   // one-pass form of the class path: sweep 1 also stores per-class sums of products (csum), the
@@ -127,7 +130,11 @@ struct temx_plan {
   // op_valid: csum (and Pq) hold the class sums of the latest temx_tem_stage1 on this plan
   bool onepass = false, op_valid = false;
   DevBuf csum, ccnt;
-  DevBuf Pq;                     // [3][K][D] projections of u v, u omega, v theta accumulated by sweep 1
+  DevBuf Pq;                     // [3][K][D] projections of the co-moments of u v, u omega, v theta (sweep 1)
+  // one-pass tracer: class sums of q ([groups][d-tiles][64] {north, south} pairs) and the projected
+  // co-moments of q v, q omega; tq_valid: they describe the latest temx_tracer_stage1_sums
+  DevBuf csq, Pq2;
+  bool tq_valid = false;
   // shared workspaces
   DevBuf partial;
   // operator-API workspace (any D)
@@ -325,7 +332,12 @@ static int launch_solve(temx_plan* pl, const double* B, int NF, int64_t D, doubl
                         hipStream_t st) {
   if (pl->K <= 64) {   // two small MFMA GEMMs per d-tile
     const int nmb = (pl->M + 3) / 4;
-    dim3 grid((unsigned)(((D + 15) / 16 + 3) / 4), NF, Xb ? (nmb + SOLVE_MB - 1) / SOLVE_MB : 1);
+    // slices of the output latitudes: every slice recomputes the coefficients (TB^2 MFMAs), so slices
+    // are as tall as the LDS image allows (SOLVE_MB) unless the grid would leave most of the chip idle
+    const int gx = (int)(((D + 15) / 16 + 3) / 4);
+    int mbs = SOLVE_MB;
+    while (mbs > 4 && (int64_t)gx * NF * ((nmb + mbs - 1) / mbs) < pl->num_cu / 2) mbs -= 4;
+    dim3 grid((unsigned)gx, NF, Xb ? (nmb + mbs - 1) / mbs : 1);
 #define TEMX_LS(TBv)                                                                                  \
   do {                                                                                                \
     const size_t slds = ((size_t)TBv * TBv + (size_t)SOLVE_MB * TBv) * 16 * sizeof(double);           \
@@ -333,7 +345,7 @@ static int launch_solve(temx_plan* pl, const double* B, int NF, int64_t D, doubl
     if (int rc_ = lds_attr_once(attr, pl->device, reinterpret_cast<const void*>(solve_mfma_kernel<TBv>), (int)slds)) \
       return rc_;                                                                                     \
     hipLaunchKernelGGL(solve_mfma_kernel<TBv>, grid, dim3(256), slds, st, B, pl->K, pl->M, D,         \
-                       pl->gblk.d(), pl->ypblk.d(), C, Xb);                                           \
+                       pl->gblk.d(), pl->ypblk.d(), C, Xb, mbs);                                      \
   } while (0)
     switch (pl->TB) {
       case 4: TEMX_LS(4); break;
@@ -656,7 +668,7 @@ static int class_cuts(temx_plan* pl, int nsub, const int2** out, bool group_alig
 #define TEMX_CLS_E_PD_F32 4
 #endif
 #ifndef TEMX_CLS_Q_PD_F32
-#define TEMX_CLS_Q_PD_F32 4
+#define TEMX_CLS_Q_PD_F32 2
 #endif
 constexpr int CLS_PROJ_E_WPS = TEMX_CLS_E_WPS, CLS_PROJ_E_PD = TEMX_CLS_E_PD;   // one field per wave
 // X batches a wave of the class project sweep holds (PD - 1 in flight).  A batch of fp32 carries half
@@ -671,26 +683,14 @@ constexpr int cls_proj_pd(bool op, int nfw) {
 
 template <typename T, int NF>
 static int launch_project_cls_t(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t D, const double* colscale,
-                                int sfield, double* partial, const Split& sp, hipStream_t st, double* csum) {
+                                int sfield, double* partial, const Split& sp, hipStream_t st) {
   const int2* cuts = nullptr;
-  if (int rc = class_cuts(pl, sp.nsplit, &cuts, csum != nullptr)) return rc;
+  if (int rc = class_cuts(pl, sp.nsplit, &cuts)) return rc;
   dim3 grid(sp.grid), block(256);
 #define TEMX_LPC(TBSv, NFWv, WPSv, OPv)                                                             \
   hipLaunchKernelGGL((project_cls_kernel<T, NF, NFWv, TBSv, WPSv, cls_proj_pd<T>(OPv, NFWv), OPv>), grid, block, 0, st, fp, D, pl->K, \
                      pl->ycls.d(), static_cast<const int4*>(pl->crow.p), cuts, colscale, sfield,    \
-                     partial, sp.nsplit, sp.ndt, csum)
-  if constexpr (NF == 4) {
-    if (csum != nullptr) {          // one-pass form: quads of d-tiles, all four fields per wave
-      switch (pl->TBS) {
-        case 2: TEMX_LPC(2, 4, TEMX_CLS_OP_WPS, true); break;
-        case 4: TEMX_LPC(4, 4, TEMX_CLS_OP_WPS, true); break;
-        case 7: TEMX_LPC(7, 4, TEMX_CLS_OP_WPS, true); break;
-        default: TEMX_LPC(8, 4, TEMX_CLS_OP_WPS, true); break;
-      }
-      HIPCHK(hipGetLastError());
-      return TEMX_OK;
-    }
-  }
+                     partial, sp.nsplit, sp.ndt, (double*)nullptr)
   if (NF == 1 || sp.dpw == 1) {     // one field per wave (NF = 4: small ragged D, one d-tile per workgroup)
     switch (pl->TBS) {
       case 2: TEMX_LPC(2, 1, CLS_PROJ_E_WPS, false); break;
@@ -714,9 +714,68 @@ static int launch_project_cls_t(temx_plan* pl, const FieldPtrs<NF>& fp, int64_t 
 template <int NF>
 static int launch_project_cls(temx_plan* pl, const FieldPtrs<NF>& fp, int dtype, int64_t D,
                               const double* colscale, int sfield, double* partial, const Split& sp,
-                              hipStream_t st, double* csum = nullptr) {
-  if (dtype == TEMX_F64) return launch_project_cls_t<double, NF>(pl, fp, D, colscale, sfield, partial, sp, st, csum);
-  if (dtype == TEMX_F32) return launch_project_cls_t<float, NF>(pl, fp, D, colscale, sfield, partial, sp, st, csum);
+                              hipStream_t st) {
+  if (dtype == TEMX_F64) return launch_project_cls_t<double, NF>(pl, fp, D, colscale, sfield, partial, sp, st);
+  if (dtype == TEMX_F32) return launch_project_cls_t<float, NF>(pl, fp, D, colscale, sfield, partial, sp, st);
+  return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
+}
+
+// one-pass sweep 1 (kernels_op.hpp): the row table as 64-bit element offsets row * D with the batch flags
+static int build_op_table(temx_plan* pl) {
+  const size_t n = pl->crow_host.size();
+  if (n == 0 || n % 16) return fail(TEMX_ESTATE, "no class table");
+  std::vector<int64_t> t(n);
+  bool prev_south = false;
+  for (size_t b = 0; b < n / 16; ++b) {
+    const int fl = (pl->crow_host[b * 16] >> 28) & 7;
+    bool pad = false;
+    for (int e = 0; e < 16; ++e) pad = pad || pl->crow_host[b * 16 + e] < 0;
+    if (fl & CLS_FIRST) prev_south = false;
+    const bool south = (fl & CLS_SOUTH) != 0;
+    int of = (south ? OPF_SOUTH : 0) | ((fl & CLS_LAST) ? OPF_LAST : 0) | (pad ? OPF_PAD : 0);
+    if ((fl & CLS_FIRST) || (south && !prev_south)) of |= OPF_SIDE0;
+    prev_south = south;
+    for (int e = 0; e < 16; ++e) {
+      const int ent = pl->crow_host[b * 16 + e];
+      int64_t v = ent < 0 ? (int64_t)0 : (int64_t)(ent & CLS_ROWMASK) * pl->D;
+      v |= (int64_t)of << 56;
+      if (ent < 0) v |= (int64_t)1 << 63;
+      t[b * 16 + e] = v;
+    }
+  }
+  return upload(pl->coff, t.data(), t.size() * sizeof(int64_t));
+}
+
+template <typename T, int KIND>
+static int launch_sweep_op_t(temx_plan* pl, const FieldPtrs<4>& fp, double* partial, const Split& sp, double* sums,
+                             hipStream_t st) {
+  const int2* cuts = nullptr;
+  if (int rc = class_cuts(pl, sp.nsplit, &cuts, true)) return rc;
+  dim3 grid(sp.grid), block(256);
+  // the tracer sweep (42 accumulators) runs two waves per SIMD: a ring of 2 batches keeps it inside 256 registers
+  constexpr int PDv = KIND == 1 ? (sizeof(T) == 4 ? 4 : 2) : (sizeof(T) == 4 ? TEMX_CLS_OP_PD_F32 : TEMX_CLS_OP_PD);
+#define TEMX_LSO(TBSv)                                                                                \
+  hipLaunchKernelGGL((sweep_op_kernel<T, TBSv, PDv, KIND>), grid, block, 0, st, fp, pl->D, pl->K, pl->ycls.d(), \
+                     static_cast<const longlong2*>(pl->coff.p), cuts, pl->colscale.d(), partial, sp.nsplit,  \
+                     sp.ndt, sums)
+  switch (pl->TBS) {
+    case 2: TEMX_LSO(2); break;
+    case 4: TEMX_LSO(4); break;
+    case 7: TEMX_LSO(7); break;
+    default: TEMX_LSO(8); break;
+  }
+#undef TEMX_LSO
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+// KIND 0: (u, v, T, omega) -> csum; KIND 1: (q, v, omega) -> csq
+template <int KIND>
+static int launch_sweep_op(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, double* partial, const Split& sp,
+                           hipStream_t st) {
+  double* sums = KIND == 0 ? pl->csum.d() : pl->csq.d();
+  if (dtype == TEMX_F64) return launch_sweep_op_t<double, KIND>(pl, fp, partial, sp, sums, st);
+  if (dtype == TEMX_F32) return launch_sweep_op_t<float, KIND>(pl, fp, partial, sp, sums, st);
   return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
 }
 
@@ -759,18 +818,18 @@ static int launch_eddy_cls_t(temx_plan* pl, const FieldPtrs<4>& fp, const double
   }
 }
 
-template <int DPW>
+template <int DPW, int KIND>
 static int launch_flux_cls_d(temx_plan* pl, const double* C, double* partial, const Split& sp, hipStream_t st) {
   dim3 grid(sp.grid), block(512);
 #define TEMX_LFC(TBSv)                                                                                \
   do {                                                                                                \
-    auto kern = flux_cls_kernel<TBSv, DPW>;                                                           \
+    auto kern = flux_cls_kernel<TBSv, DPW, KIND>;                                                     \
     const size_t lds = ((size_t)DPW * 4 * 2 * TBSv * 64 + 8 * 2 * TBSv * 16) * sizeof(double);        \
     static std::atomic<uint64_t> attr_set{0};                                                         \
     if (int rc_ = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(kern), (int)lds)) \
       return rc_;                                                                                     \
     hipLaunchKernelGGL(kern, grid, block, lds, st, pl->D, pl->K, pl->K4, pl->ycls.d(), pl->csum.d(),  \
-                       pl->ccnt.d(), pl->cgroups, C, partial, sp.nsplit, sp.ndt);                     \
+                       pl->csq.d(), pl->ccnt.d(), pl->cgroups, C, partial, sp.nsplit, sp.ndt);        \
   } while (0)
   switch (pl->TBS) {
     case 2: TEMX_LFC(2); break;
@@ -783,11 +842,12 @@ static int launch_flux_cls_d(temx_plan* pl, const double* C, double* partial, co
   return TEMX_OK;
 }
 
+template <int KIND>
 static int launch_flux_cls(temx_plan* pl, const double* C, double* partial, const Split& sp, hipStream_t st) {
   switch (sp.dpw) {
-    case 1: return launch_flux_cls_d<1>(pl, C, partial, sp, st);
-    case 2: return launch_flux_cls_d<2>(pl, C, partial, sp, st);
-    default: return launch_flux_cls_d<4>(pl, C, partial, sp, st);
+    case 1: return launch_flux_cls_d<1, KIND>(pl, C, partial, sp, st);
+    case 2: return launch_flux_cls_d<2, KIND>(pl, C, partial, sp, st);
+    default: return launch_flux_cls_d<4, KIND>(pl, C, partial, sp, st);
   }
 }
 
@@ -1139,10 +1199,13 @@ void temx_plan_destroy(temx_plan* pl) {
                     &pl->Bq, &pl->Bq2, &pl->Ct, &pl->tz, &pl->rows, &pl->ysym, &pl->Bs, &pl->XB, &pl->P3};
   for (DevBuf* b : bufs) b->release();
   pl->crow.release();
+  pl->coff.release();
   pl->ycls.release();
   pl->csum.release();
   pl->ccnt.release();
   pl->Pq.release();
+  pl->csq.release();
+  pl->Pq2.release();
   pl->ycls_l.release();
   pl->pbuf.release();
   pl->gblk.release();
@@ -1270,6 +1333,7 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
     if ((!pl->large || pl->K <= 256) && !(flags & (TEMX_NO_SYMMETRY | TEMX_NO_CLASSES)) && !(e0 && e0[0] == '1') &&
         !(e1 && e1[0] == '1') && build_classes(lat_deg_host, ncol, ct)) {
       if ((rc = upload(pl->crow, ct.crow.data(), ct.crow.size() * sizeof(int)))) return bail(rc);
+      pl->crow_host = ct.crow;
       if ((rc = upload(pl->ccnt, ct.cnt.data(), ct.cnt.size() * 8))) return bail(rc);
       DevBuf xc;
       if ((rc = upload(xc, ct.xc.data(), ct.xc.size() * 8))) return bail(rc);
@@ -1502,7 +1566,7 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
   // a failure below must not leave an earlier configuration half replaced: the plan is unconfigured
   // (tem_ready fails) until the last allocation has succeeded
   pl->tem = false;
-  pl->onepass = pl->lone = pl->op_valid = pl->xb_valid = false;
+  pl->onepass = pl->lone = pl->op_valid = pl->xb_valid = pl->tq_valid = false;
   pl->nlev = nlev;
   pl->nt = nt;
   pl->D = (int64_t)nlev * nt;
@@ -1618,6 +1682,7 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
           const size_t need4 = (size_t)std::max(pl->sp_cflux.nsplit * 3, sp_op.nsplit * 7) * pl->K * D * 8;
           if ((rc = pl->partial.ensure(std::max(need4, pl->partial.bytes)))) return rc;
           if ((rc = pl->Pq.ensure((size_t)3 * pl->K * D * 8))) return rc;
+          if ((rc = build_op_table(pl))) return rc;
         }
       }
     }
@@ -1676,8 +1741,9 @@ int temx_tem_stage1(temx_plan* pl, const void* ua, const void* va, const void* t
   const Split& sp = pl->cls ? pl->sp_cproj4 : (sp4 ? pl->sp_sproj4 : pl->sp_proj4);
   const bool op = pl->cls && pl->onepass;
   pl->op_valid = false;
-  rc = pl->cls ? launch_project_cls<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->partial.d(), sp, st,
-                                       op ? pl->csum.d() : nullptr)
+  pl->tq_valid = false;          // tracer class sums pair with the v, omega sums of one TEM run
+  rc = op      ? launch_sweep_op<0>(pl, fp, dtype, pl->partial.d(), sp, st)
+       : pl->cls ? launch_project_cls<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->partial.d(), sp, st)
        : sp4   ? launch_project_sym<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->partial.d(), sp, st)
                : launch_project<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->partial.d(), sp, st);
   time_end(pl, 0, st, tl);
@@ -1792,7 +1858,7 @@ int temx_tem_stage2_from_sums(temx_plan* pl, const double* B4, double* B3, void*
   }
   TimedLaunch tl{};
   time_begin(pl, 1, st, tl);
-  rc = launch_flux_cls(pl, pl->C4.d(), pl->partial.d(), pl->sp_cflux, st);
+  rc = launch_flux_cls<0>(pl, pl->C4.d(), pl->partial.d(), pl->sp_cflux, st);
   time_end(pl, 1, st, tl);
   if (rc) return rc;
   // B3 = (projections of u v, u omega, v theta from sweep 1) + (projected corrections)
@@ -1809,14 +1875,19 @@ int temx_tem_stage3(temx_plan* pl, const double* B3, double* results, double* zo
   const int64_t MD = (int64_t)pl->M * pl->D;
   // flux zonal means upvpb upwappb vptpb -> zb[4..6]
   if ((rc = launch_solve(pl, B3, 3, pl->D, nullptr, pl->zb.d() + 4 * MD, st))) return rc;
-  // int_vbdp -> zb[7]
-  const int64_t ncols = (int64_t)pl->M * pl->nt;
-  hipLaunchKernelGGL(pint_scan_kernel, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st, pl->zb.d() + 1 * MD,
-                     pl->p.d(), pl->M, pl->nlev, pl->nt, pl->zb.d() + 7 * MD);
-  HIPCHK(hipGetLastError());
+  // int_vbdp -> zb[7]: by a wavefront scan for tall columns, inside the epilogue otherwise (one launch fewer)
   EpiTables tb{pl->p.d(), pl->pg.d(), pl->lg.d(), pl->coslat.d(), pl->fcor.d()};
-  hipLaunchKernelGGL(tem_epilogue_kernel, dim3((unsigned)((MD + 255) / 256)), dim3(256), 0, st, pl->zb.d(),
-                     pl->M, pl->nlev, pl->nt, tb, pl->p0, results, zonal);
+  if (pl->nlev > 192) {
+    const int64_t ncols = (int64_t)pl->M * pl->nt;
+    hipLaunchKernelGGL(pint_scan_kernel, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st, pl->zb.d() + 1 * MD,
+                       pl->p.d(), pl->M, pl->nlev, pl->nt, pl->zb.d() + 7 * MD);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(tem_epilogue_kernel<false>, dim3((unsigned)((MD + 255) / 256)), dim3(256), 0, st, pl->zb.d(),
+                       pl->M, pl->nlev, pl->nt, tb, pl->p0, results, zonal);
+  } else {
+    hipLaunchKernelGGL(tem_epilogue_kernel<true>, dim3((unsigned)((MD + 255) / 256)), dim3(256), 0, st, pl->zb.d(),
+                       pl->M, pl->nlev, pl->nt, tb, pl->p0, results, zonal);
+  }
   HIPCHK(hipGetLastError());
   return TEMX_OK;
 }
@@ -1959,11 +2030,61 @@ int temx_tracer_stage3(temx_plan* pl, const double* Bq2, double* tres, double* t
   return TEMX_OK;
 }
 
+static inline bool tracer_one_pass(const temx_plan* pl) { return pl->cls && pl->onepass && pl->op_valid; }
+
+int temx_tracer_stage1_sums(temx_plan* pl, const void* q, const void* va, const void* wap, int dtype,
+                            double* Bq, void* stream) {
+  int rc = tem_ready(pl);
+  if (rc) return rc;
+  if (!q || !va || !wap || !Bq) return fail(TEMX_EINVAL, "null argument");
+  if (!tracer_one_pass(pl))
+    return fail(TEMX_ESTATE, "needs the one-pass class path and the class sums of a TEM run on this plan "
+                             "(temx_plan_one_pass, temx_tem_stage1)");
+  HIPCHK(hipSetDevice(pl->device));
+  if ((rc = tracer_ws(pl))) return rc;
+  hipStream_t st = S_(stream);
+  const Split& sp = pl->sp_cproj4;
+  const int64_t KD = (int64_t)pl->K * pl->D;
+  if ((rc = pl->csq.ensure((size_t)pl->cgroups * sp.ndt * 2 * 64 * 8))) return rc;
+  if ((rc = pl->Pq2.ensure((size_t)2 * KD * 8))) return rc;
+  pl->tq_valid = false;
+  // one read of (q, v, omega): 3 slabs per split -- q, then the co-moments of q v and q omega
+  if ((rc = launch_sweep_op<1>(pl, four(q, va, wap, nullptr), dtype, pl->partial.d(), sp, st))) return rc;
+  if ((rc = launch_reduce(pl, pl->partial.d(), sp.nsplit, KD, Bq, st, 3 * KD))) return rc;
+  if ((rc = launch_reduce(pl, pl->partial.d() + KD, sp.nsplit, 2 * KD, pl->Pq2.d(), st, 3 * KD))) return rc;
+  pl->tq_valid = true;
+  return TEMX_OK;
+}
+
+int temx_tracer_stage2_from_sums(temx_plan* pl, const double* Bq, double* Bq2, void* stream) {
+  int rc = tem_ready(pl);
+  if (rc) return rc;
+  if (!Bq || !Bq2) return fail(TEMX_EINVAL, "null argument");
+  if (!tracer_one_pass(pl) || !pl->tq_valid)
+    return fail(TEMX_ESTATE, "no tracer class sums: temx_tracer_stage1_sums must precede temx_tracer_stage2_from_sums");
+  HIPCHK(hipSetDevice(pl->device));
+  hipStream_t st = S_(stream);
+  const size_t slab = (size_t)pl->K4 * pl->D * 8;
+  // coefficients: Ct = (C_q, C_v, C_w); qb -> tz[0]
+  if ((rc = launch_solve(pl, Bq, 1, pl->D, pl->Ct.d(), pl->tz.d(), st))) return rc;
+  HIPCHK(hipMemcpyAsync((char*)pl->Ct.p + slab, (char*)pl->C4.p + slab, slab, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync((char*)pl->Ct.p + 2 * slab, (char*)pl->C4.p + 3 * slab, slab, hipMemcpyDeviceToDevice, st));
+  if ((rc = launch_flux_cls<1>(pl, pl->Ct.d(), pl->partial.d(), pl->sp_cflux, st))) return rc;
+  // Bq2 = (projected co-moments of q v, q omega from the sweep) + (projected n (m_q - qb)(m_v - vb) terms)
+  return launch_reduce(pl, pl->partial.d(), pl->sp_cflux.nsplit, (int64_t)2 * pl->K * pl->D, Bq2, st, -1,
+                       pl->Pq2.d());
+}
+
 int temx_tracer_run(temx_plan* pl, const void* q, const void* va, const void* wap, int dtype,
                     double* tres, double* tzon, void* stream) {
   int rc = tem_ready(pl);
   if (rc) return rc;
   if ((rc = tracer_ws(pl))) return rc;
+  if (tracer_one_pass(pl)) {     // (q, v, omega) are read once; needs the TEM run's sums of v and omega
+    if ((rc = temx_tracer_stage1_sums(pl, q, va, wap, dtype, pl->Bq.d(), stream))) return rc;
+    if ((rc = temx_tracer_stage2_from_sums(pl, pl->Bq.d(), pl->Bq2.d(), stream))) return rc;
+    return temx_tracer_stage3(pl, pl->Bq2.d(), tres, tzon, stream);
+  }
   if ((rc = temx_tracer_stage1(pl, q, dtype, pl->Bq.d(), stream))) return rc;
   if ((rc = temx_tracer_stage2(pl, q, va, wap, dtype, pl->Bq.d(), pl->Bq2.d(), stream))) return rc;
   return temx_tracer_stage3(pl, pl->Bq2.d(), tres, tzon, stream);

@@ -258,6 +258,18 @@ class Plan:
                                           _ptr(Bq2), self._stream()))
         return Bq2
 
+    def tracer_stage1_sums(self, q, va, wap):
+        """One-pass stage 1 (needs ``one_pass`` and a preceding TEM stage 1 / run on the same va, wap)."""
+        (qq, v, w), dt = self._three(q, va, wap)
+        Bq = torch.empty((self.K, self.D), dtype=torch.float64, device=self.device)
+        check(self.lib.temx_tracer_stage1_sums(self._h, _ptr(qq), _ptr(v), _ptr(w), dt, _ptr(Bq), self._stream()))
+        return Bq
+
+    def tracer_stage2_from_sums(self, Bq):
+        Bq2 = torch.empty((2, self.K, self.D), dtype=torch.float64, device=self.device)
+        check(self.lib.temx_tracer_stage2_from_sums(self._h, _ptr(Bq.contiguous()), _ptr(Bq2), self._stream()))
+        return Bq2
+
     def tracer_stage3(self, Bq2, want_zonal=False):
         tres = torch.empty((len(_lib.TRACER_RESULT_NAMES), self.M, self.nlev, self.nt), dtype=torch.float64,
                            device=self.device)

@@ -60,3 +60,15 @@ def read_dataset(path):
             a = np.array(var[:])
             out[name] = (tuple(var.dimensions), a.astype(a.dtype.newbyteorder("=")))
     return out
+
+
+def read_any(path):
+    """Like :func:`read_dataset`, for NetCDF-3 (scipy) and -- when xarray is importable -- NetCDF-4 files
+    (the reference writes its map cache through xarray, sph_zonal_mean.py:400-417)."""
+    with open(path, "rb") as fh:
+        magic = fh.read(4)
+    if magic[:3] == b"CDF":
+        return read_dataset(path)
+    import xarray as xr                      # NetCDF-4 / HDF5: needs xarray + netCDF4 or h5netcdf
+    with xr.open_dataset(path) as ds:
+        return {k: (tuple(v.dims), np.asarray(v.values)) for k, v in ds.variables.items()}

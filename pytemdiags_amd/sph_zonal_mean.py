@@ -30,10 +30,17 @@ class sph_zonal_averager:
     """Zonal averaging on an unstructured grid by projection on the Y_l^0 (sph_zonal_mean.py:35).
 
     Extra keyword (not in the reference): ``device`` -- CUDA device index (default 0).
-    The NetCDF map cache arguments (``grid_name``, ``grid_out_name``, ``save_dest``,
-    ``overwrite``) are accepted and the cache file names are derived exactly like the reference
-    (sph_zonal_mean.py:165-174), but nothing is read or written: rebuilding the basis on the
-    device takes < 1 ms, so ``sph_compute_matrices`` always computes.
+
+    Map cache (sph_zonal_mean.py:329-345, 400-417).  The cache file names are derived exactly like the
+    reference (:165-174) and the files hold the same variables -- ``Y0[ncol, l]`` and ``Y0inv[l, ncol]``
+    in ``Y0_{grid}_L{L}.nc``, ``Y0p[ncol, l]`` in ``Y0p_{grid}_{gridout}_L{L}.nc``.  Two deliberate
+    differences: (1) the cache is used only when ``save_dest`` is given -- the reference defaults to a
+    ``maps`` directory next to the package and always writes, but the dense ``Y0inv`` is K x N doubles
+    (317 MB at ne120) that this engine never needs, and rebuilding the basis on the device takes
+    < 1 ms; (2) without netCDF4 / xarray the files are NetCDF-3 (``scipy.io``), which xarray reads
+    back, while a NetCDF-4 file written by the reference can only be read here when xarray is
+    importable.  Matrices read from the cache are checked against the device-built basis; a file
+    that belongs to another grid or L is reported and ignored (the reference would use it silently).
     """
 
     def __init__(self, lat, lat_out, L, weights=None, grid_name=None, grid_out_name=None,
@@ -51,6 +58,7 @@ class sph_zonal_averager:
         self.logfile = logfile
         self.device = 0 if device is None else device
 
+        self._cache_on = save_dest is not None       # see the class docstring
         self.N = len(self.lat)                       # :154
         self.M = len(self.lat_out)                   # :155
         self.l = np.arange(L + 1)                    # :156
@@ -97,10 +105,44 @@ class sph_zonal_averager:
             return self.Y0.T * self.weights[None, :]
         return self._matrix(_lib.MAT_Y0INV)
 
+    # ---- map cache files (sph_zonal_mean.py:329-345, 400-417) ----
+    def _read_map_cache(self):
+        """(Y0, Y0inv, Y0p) from the cache files, or None (missing, unreadable or of another shape)."""
+        import os
+        from . import ncio
+        if not (os.path.isfile(self.Y0_file_out) and os.path.isfile(self.Y0p_file_out)):
+            return None
+        try:
+            a, b = ncio.read_any(self.Y0_file_out), ncio.read_any(self.Y0p_file_out)
+            Y0, Y0inv, Y0p = a["Y0"][1], a["Y0inv"][1], b["Y0p"][1]
+        except Exception:   # noqa: BLE001 - an unreadable cache is no cache (e.g. NetCDF-4 without netCDF4)
+            return None
+        K = self.L + 1
+        if Y0.shape != (self.N, K) or Y0inv.shape != (K, self.N) or Y0p.shape != (self.M, K):
+            return None
+        return Y0, Y0inv, Y0p
+
+    def _write_map_cache(self):
+        import os
+        from . import ncio
+        os.makedirs(self.save_dest, exist_ok=True)
+        ncio.write_dataset(self.Y0_file_out, {
+            "Y0": (("ncol", "l"), self.Y0, {"long_name": "Matrix Y0 for grid {}".format(self.grid_name)}),
+            "Y0inv": (("l", "ncol"), self.Y0inv, {"long_name": "Matrix Y0inv for grid {}".format(self.grid_name)})})
+        ncio.write_dataset(self.Y0p_file_out, {
+            "Y0p": (("ncol", "l"), self.Y0p, {"long_name": "Matrix Y0p for grid {}".format(self.grid_out_name)})})
+
     def sph_compute_matrices(self, overwrite=False, read_only=False, no_write=False):
-        """Build Y0, Y0p and the (factorised) inverse on the device (sph_zonal_mean.py:302-422)."""
-        if read_only:
-            return                                   # nothing is cached on file (:343-345)
+        """Build Y0, Y0p and the (factorised) inverse on the device (sph_zonal_mean.py:302-422); with a
+        ``save_dest``, read / write the reference's map cache files around it."""
+        import os
+        if self._cache_on and overwrite:             # :332-334
+            for fn in (self.Y0_file_out, self.Y0p_file_out):
+                if os.path.isfile(fn):
+                    os.remove(fn)
+        cached = self._read_map_cache() if self._cache_on else None
+        if read_only and cached is None:
+            return                                   # no cache on file (:343-345)
         from . import engine
         if self.weights is not None and len(self.weights) != len(self.lat):
             raise RuntimeError("number of weights must equal number of native grid latitudes!")   # :353-354
@@ -111,6 +153,22 @@ class sph_zonal_averager:
                                  defer_finalize=self.weights is not None)
         if self.weights is not None:
             self._plan.set_weights(self.weights / (4 * np.pi))
+        if cached is not None:
+            # the engine applies its own factorisation of the same operator; a cache is accepted only if
+            # it describes this grid and L
+            ok = (np.max(np.abs(cached[0] - self.Y0)) <= 1e-9 and np.max(np.abs(cached[2] - self.Y0p)) <= 1e-9
+                  and np.max(np.abs(cached[1] @ cached[0] - np.eye(self.L + 1))) <= 1e-6)
+            if ok:
+                self._cache[_lib.MAT_Y0], self._cache[_lib.MAT_Y0P] = cached[0], cached[2]
+                if self.weights is None:
+                    self._cache[_lib.MAT_Y0INV] = cached[1]
+                self.map_cache_used = True
+                return
+            import warnings
+            warnings.warn("map cache {} does not match this grid / L; recomputed".format(self.Y0_file_out))
+        self.map_cache_used = False
+        if self._cache_on and not no_write and not read_only:
+            self._write_map_cache()                  # :400-417
 
     def sanity_check(self):
         """(sum(diag(Y0inv Y0)), sum(offdiag)) -- the numbers the reference prints (:393-398)."""

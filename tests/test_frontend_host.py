@@ -179,3 +179,18 @@ def test_ncio_round_trip(tmp_path):
     assert "time" not in ds                                 # no coordinate given for it
     with pytest.raises(ValueError):
         ncio.write_dataset(str(tmp_path / "b.nc"), {"x": (("lat", "plev"), x)})
+
+
+def test_map_cache_file_format_host(tmp_path):
+    """ncio writes / reads the map-cache variables of sph_zonal_mean.py:400-417 (host only, NetCDF-3)."""
+    from pytemdiags_amd import ncio
+    rng = np.random.default_rng(0)
+    Y0, Y0inv = rng.standard_normal((40, 7)), rng.standard_normal((7, 40))
+    p = ncio.write_dataset(str(tmp_path / "Y0_g_L6.nc"), {
+        "Y0": (("ncol", "l"), Y0, {"long_name": "Matrix Y0 for grid g"}),
+        "Y0inv": (("l", "ncol"), Y0inv, {"long_name": "Matrix Y0inv for grid g"})})
+    d = ncio.read_any(p)
+    assert d["Y0"][0] == ("ncol", "l") and d["Y0inv"][0] == ("l", "ncol")
+    assert np.array_equal(d["Y0"][1], Y0) and np.array_equal(d["Y0inv"][1], Y0inv)
+    with open(p, "rb") as fh:
+        assert fh.read(3) == b"CDF"

@@ -262,3 +262,48 @@ def test_native_attributes_stream_in_column_blocks():
     assert seen == 866
     for n in NATIVE:
         assert fieldnorm_err(whole[n], g["nat_" + n]) <= 2e-5
+
+
+def test_map_cache_files_round_trip(tmp_path):
+    """The reference's NetCDF map cache (sph_zonal_mean.py:329-345, 400-417): file names, variables
+    ``Y0[ncol, l]``, ``Y0inv[l, ncol]``, ``Y0p[ncol, l]``; written after the build, read back by the next
+    averager, deleted by ``overwrite``; a cache of another L is ignored."""
+    import os
+    from pytemdiags_amd import sph_zonal_averager, ncio
+    g = load("op_ne4_L30")
+    L = int(g["L"])
+    dest = str(tmp_path / "maps")
+    Z = sph_zonal_averager(g["lat"], g["lat_out"], L, save_dest=dest, grid_name="ne4np4", grid_out_name="2deg")
+    assert Z.Y0 is None                                    # nothing cached yet (read_only probe, :177)
+    Z.sph_compute_matrices()
+    assert Z.Y0_file_out == "%s/Y0_ne4np4_L%d.nc" % (dest, L)
+    assert Z.Y0p_file_out == "%s/Y0p_ne4np4_2deg_L%d.nc" % (dest, L)
+    assert os.path.isfile(Z.Y0_file_out) and os.path.isfile(Z.Y0p_file_out) and not Z.map_cache_used
+    a, b = ncio.read_dataset(Z.Y0_file_out), ncio.read_dataset(Z.Y0p_file_out)
+    assert a["Y0"][0] == ("ncol", "l") and a["Y0inv"][0] == ("l", "ncol") and b["Y0p"][0] == ("ncol", "l")
+    assert np.max(np.abs(a["Y0"][1] - g["Y0"])) < 2e-12 and np.max(np.abs(b["Y0p"][1] - g["Y0p"])) < 2e-12
+    assert np.max(np.abs(a["Y0inv"][1] @ a["Y0"][1] - np.eye(L + 1))) < 1e-10
+    # a second averager finds the cache in its constructor, like the reference
+    Z2 = sph_zonal_averager(g["lat"], g["lat_out"], L, save_dest=dest, grid_name="ne4np4", grid_out_name="2deg")
+    assert Z2.map_cache_used and np.array_equal(Z2.Y0, a["Y0"][1]) and np.array_equal(Z2.Y0inv, a["Y0inv"][1])
+    zm = Z2.sph_zonal_mean(g["in_rand3d"])
+    assert np.max(np.abs(zm - g["zm_rand3d"])) <= 1e-10 * max(1.0, float(np.max(np.abs(g["in_rand3d"]))))
+    # overwrite deletes and rebuilds (:332-334); no_write leaves no file
+    t0 = os.path.getmtime(Z.Y0_file_out)
+    Z3 = sph_zonal_averager(g["lat"], g["lat_out"], L, save_dest=dest, grid_name="ne4np4", grid_out_name="2deg",
+                            overwrite=True)
+    assert Z3.Y0 is None and not os.path.isfile(Z.Y0_file_out)
+    Z3.sph_compute_matrices(no_write=True)
+    assert not os.path.isfile(Z.Y0_file_out) and Z3.Y0 is not None
+    # a file of the right name but another grid is reported and ignored
+    Z.sph_compute_matrices()
+    assert os.path.getmtime(Z.Y0_file_out) >= t0
+    lat_other = g["lat"][::-1].copy()
+    with pytest.warns(UserWarning):
+        Z4 = sph_zonal_averager(lat_other, g["lat_out"], L, save_dest=dest, grid_name="ne4np4", grid_out_name="2deg")
+    assert not Z4.map_cache_used
+    assert np.max(np.abs(Z4.sph_zonal_mean(g["in_rand3d"][::-1]) - g["zm_rand3d"])) <= 1e-10 * 5
+    # without save_dest nothing is read or written (see the class docstring)
+    Z5 = sph_zonal_averager(g["lat"], g["lat_out"], L)
+    Z5.sph_compute_matrices()
+    assert not os.path.exists(Z5.Y0_file_out)

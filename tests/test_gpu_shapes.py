@@ -544,3 +544,57 @@ def test_fuzz_random_grids_and_shapes(seed, monkeypatch):
         e = fieldnorm_err(zon[i].cpu().numpy(), getattr(ref, n))
         assert e <= tol, (n, e) + info
     plan.close()
+
+
+def test_one_pass_tracer_reads_the_fields_once(force_one_pass):
+    """Tracer TEM on the one-pass class path (tem_diagnostics.py:532-538, 560-570): temx_tracer_stage1_sums
+    reads (q, v, omega) once and stores the class sums of q; temx_tracer_stage2_from_sums forms the
+    q'v', q'omega' sums from them and the TEM run's class sums of v and omega.  Against the oracle, against
+    the two-pass stages, and the state checks of the explicit contract."""
+    from oracle import tem_oracle as orc
+    from pytemdiags_amd import _lib, engine, synth
+    lat, lon = synth.cubed_sphere_gll(8)
+    plev = synth.pressure_levels(16)
+    nt = 4
+    f = synth.analytic_fields(lat, lon, plev, nt, seed=21)
+    qs = [synth.analytic_tracer(lat, lon, plev, nt, which=i) for i in range(2)]
+    ref = orc.TEMOracle(*f, lat, plev, mode="factorised", q=qs)
+    plan = engine.Plan(lat, ref.lat, 50)
+    plan.set_tem(16, nt, plev * 100)
+    d = [torch.as_tensor(x, device="cuda:0") for x in f]
+    dq = [torch.as_tensor(x, device="cuda:0") for x in qs]
+    if not plan.one_pass:                       # TEMX_NO_CLS / TEMX_TWO_PASS runs of the suite
+        with pytest.raises(_lib.TemxError):
+            plan.tracer_stage1_sums(dq[0], d[1], d[3])
+        plan.close()
+        return
+    with pytest.raises(_lib.TemxError):         # no TEM run yet: no class sums of v and omega
+        plan.tracer_stage1_sums(dq[0], d[1], d[3])
+    plan.tem_run(*d)
+    for i in range(2):
+        tres, tzon = plan.tracer_run(dq[i], d[1], d[3], want_zonal=True)
+        for k, n in enumerate(_lib.TRACER_RESULT_NAMES):
+            e = fieldnorm_err(tres[k].cpu().numpy(), getattr(ref, n)(i))
+            assert e <= 1e-10, (i, n, e)
+        for k, n in enumerate(_lib.TRACER_ZONAL_NAMES):
+            e = fieldnorm_err(tzon[k].cpu().numpy(), getattr(ref, n)[i])
+            assert e <= 1e-10, (i, n, e)
+        # staged form == fused form, bit for bit; two-pass stages agree to rounding
+        Bq = plan.tracer_stage1_sums(dq[i], d[1], d[3])
+        Bq2 = plan.tracer_stage2_from_sums(Bq)
+        t2, _ = plan.tracer_stage3(Bq2)
+        assert torch.equal(t2, tres)
+        Bq_b = plan.tracer_stage1(dq[i])
+        Bq2_b = plan.tracer_stage2(dq[i], d[1], d[3], Bq_b)
+        assert float((Bq_b - Bq).abs().max()) <= 1e-12 * float(Bq.abs().max())
+        assert float((Bq2_b - Bq2).abs().max()) <= 1e-11 * float(Bq2.abs().max())
+        # the native-grid tracer eddies still come from the two-pass kernel
+        ed = plan.tracer_eddy(dq[i], d[1], d[3])
+        assert fieldnorm_err(ed["qpvp"].cpu().numpy(), ref.qpvp[i]) <= 1e-10
+    # a new TEM stage 1 voids the tracer sums (they pair with one TEM run's sums of v and omega)
+    Bq = plan.tracer_stage1_sums(dq[0], d[1], d[3])
+    plan.tem_stage1(*d)
+    with pytest.raises(_lib.TemxError):
+        plan.tracer_stage2_from_sums(Bq)
+    assert not plan.status()
+    plan.close()
