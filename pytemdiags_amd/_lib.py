@@ -96,6 +96,8 @@ def load():
         pass
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SIGNATURES:
+        if "TEMX_LIB" in os.environ and not hasattr(lib, name):
+            continue                     # A/B builds of an older source tree (development only)
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args

@@ -15,9 +15,9 @@
 //   k dimension) have equal counts; a group is walked in batches of CLS_MB member rows per class,
 //   first its northern batches, then its southern ones.
 //   crow[batch][g][j]  int32: member row j of class g of the batch's group (one int4 per 16-lane
-//                      group), | side << 28 | first-batch-of-group << 29 | last << 30; bit 31 =
-//                      padding (no member: row 0 is read and weighted 0).  Every entry of a batch
-//                      carries the batch flags.  Padded by CLS_PADB batches.
+//                      group), | batch-has-padding << 27 | side << 28 | first-batch-of-group << 29 |
+//                      last << 30; bit 31 = padding entry (no member: row 0 is read and weighted 0).
+//                      Every entry of a batch carries the batch flags.  Padded by CLS_PADB batches.
 //   ycls[group][2*TBS][16]  4x4 blocks at the class latitudes, layout of kernels_sym.hpp's ysym.
 //   csplit[nsub+1]     (first batch, its group) of every piece of work; equal batch counts, cuts may
 //                      fall inside a group (both sweeps are linear in the member rows).
@@ -66,7 +66,8 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for<N, I + 1>(f);
   }
 }
-constexpr int CLS_ROWMASK = 0x0FFFFFFF;
+constexpr int CLS_ROWMASK = 0x07FFFFFF;
+constexpr int CLS_HASPAD_BIT = 1 << 27;       // the batch has at least one padding entry (set in all its entries)
 constexpr int CLS_SOUTH = 1, CLS_FIRST = 2, CLS_LAST = 4;   // flags, stored at bit 28
 
 __global__ void cls_basis_kernel(const double* __restrict__ xc, int64_t ncls, int64_t ncls_pad, int K, int TBS,

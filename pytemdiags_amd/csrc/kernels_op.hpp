@@ -10,21 +10,18 @@
 // This is the dominant kernel of the pipeline and an HBM stream, but with one wave per SIMD (98 fp64
 // accumulators) every VALU instruction sits on the critical path next to the loads, so the loop body is
 // kept lean:
-//   * the row table holds 64-bit ELEMENT OFFSETS row * D (built by temx_plan_set_tem), so a load
-//     address is one v_lshl_add_u64 -- no 64-bit multiply per row;
+//   * D is passed as 32 bits, so the element offset of a member row is one v_mad_u64_u32;
 //   * the sums of the side being walked live in ONE set of registers (no per-batch north / south
 //     selects); they move to the "north" set when the southern batches of the group begin;
 //   * batches without padding entries (the rule: cubed-sphere classes have 8 members a side) skip the
 //     member weights.
-// Entry layout of coff[batch][class g][member j] (int64):  bits 0..55 row * D, bits 56..59 the batch
-// flags (replicated in every entry of the batch), bit 63 = padding entry (reads row 0, weighs nothing).
+// Row table: crow of kernels_cls.hpp (one int4 of member rows per class and batch, batch flags in the
+// top bits of every entry).
 #pragma once
 #include "kernels_cls.hpp"
 
 namespace temx {
 
-constexpr int OPF_SOUTH = 1, OPF_SIDE0 = 2, OPF_LAST = 4, OPF_PAD = 8;   // batch flags (bits 56..59)
-constexpr int64_t OPF_OFFMASK = ((int64_t)1 << 56) - 1;
 
 // KIND 0: TEM     fields (u, v, T -> theta, omega); stored sums of all four; co-moments u v, u omega, v theta
 // KIND 1: tracer  fields (q, v, omega); stored sum of q only (those of v and omega are in the TEM run's
@@ -44,7 +41,7 @@ template <> struct OpKind<1> {
 template <typename T, int TBS, int PD, int KIND>
 __global__ void __launch_bounds__(256, OpKind<KIND>::WPS)
 sweep_op_kernel(FieldPtrs<4> fp, int64_t D, int K, const double* __restrict__ ycls,
-                const longlong2* __restrict__ coff /* [batch][4][2] pairs of entries */,
+                const int4* __restrict__ crow,
                 const int2* __restrict__ csplit, const double* __restrict__ colscale,
                 double* __restrict__ partial, int nsplit, int ndt, double* __restrict__ csum) {
   using KD = OpKind<KIND>;
@@ -54,7 +51,7 @@ sweep_op_kernel(FieldPtrs<4> fp, int64_t D, int K, const double* __restrict__ yc
   constexpr int MB = CLS_MB;
   constexpr int NFLD = KD::NFLD, NST = KD::NST, NQ = KD::NQ;
   constexpr int NA = NST + NQ;                // projections: the stored sums, then the co-moments
-  static_assert(MB == 4, "a lane group reads its 4 member entries as two 16-byte pairs");
+  static_assert(MB == 4, "a lane group reads its 4 member rows as one int4");
   static_assert(PD + 1 <= CLS_PADB, "table padding must cover the index prefetch");
   __shared__ double ystage[4][YE];            // wave private
   int split, dq;
@@ -92,21 +89,22 @@ sweep_op_kernel(FieldPtrs<4> fp, int64_t D, int K, const double* __restrict__ yc
 #pragma unroll
   for (int f = 0; f < NST; ++f) sN[f] = 0.0;
   bool north_open = false;                    // uniform: the side being walked is a northern one
+  bool prev_south = false;                    // uniform: the previous batch of this group was a southern one
+  const uint32_t D32 = (uint32_t)D;           // host guarantees D < 2^28
 
   T xb[PD][MB][NFLD];
-  int er[PD][MB];                             // high dwords of the entries: batch flags (bits 24..27), padding (sign)
+  int er[PD][MB];                             // table entries: row (27 bits), batch flags, padding (sign)
   double ys[YJ];
   auto load_ys = [&](int gi) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < YJ; ++j) ys[j] = (ycls + (int64_t)gi * YE)[(lane + 64 * j) < YE ? (lane + 64 * j) : 0];
   };
-  auto issue = [&](auto pc, const longlong2 ra, const longlong2 rb) __attribute__((always_inline)) {
+  auto issue = [&](auto pc, const int4 rv) __attribute__((always_inline)) {
     constexpr int P = decltype(pc)::value;
-    const int64_t ent[MB] = {ra.x, ra.y, rb.x, rb.y};
+    er[P][0] = rv.x; er[P][1] = rv.y; er[P][2] = rv.z; er[P][3] = rv.w;
 #pragma unroll
     for (int j = 0; j < MB; ++j) {
-      er[P][j] = (int)(ent[j] >> 32);
-      const int64_t off = ent[j] & OPF_OFFMASK;
+      const uint64_t off = (uint64_t)(uint32_t)(er[P][j] & CLS_ROWMASK) * D32;
 #pragma unroll
       for (int f = 0; f < NFLD; ++f) xb[P][j][f] = TEMX_XLOAD(fb[f] + off);
     }
@@ -124,23 +122,24 @@ sweep_op_kernel(FieldPtrs<4> fp, int64_t D, int K, const double* __restrict__ yc
     for (int k = 0; k < NQ; ++k) q[k] = 0.0;
     cnt = 0.0;
   };
-  longlong2 rna, rnb;
+  int4 rn;
   auto step = [&](auto pc, int b) __attribute__((always_inline)) {
     constexpr int P = decltype(pc)::value;
     if (b + (PD - 1) < b1) {                  // index load first: it must not queue behind the X loads
-      const longlong2 ra = rna, rb = rnb;
-      rna = coff[((int64_t)(b + PD) * 4 + g) * 2];
-      rnb = coff[((int64_t)(b + PD) * 4 + g) * 2 + 1];
-      issue(std::integral_constant<int, (P + PD - 1) % PD>{}, ra, rb);
+      const int4 r1 = rn;
+      rn = crow[(int64_t)(b + PD) * 4 + g];
+      issue(std::integral_constant<int, (P + PD - 1) % PD>{}, r1);
     }
-    const int flags = (__builtin_amdgcn_readfirstlane(er[P][0]) >> 24) & 15;
-    if (flags & OPF_SIDE0) {                  // first batch of a side: its first member is the origin
-      if ((flags & OPF_SOUTH) && north_open) finish_side(sN, qN);
-      north_open = !(flags & OPF_SOUTH);
+    const int fl = __builtin_amdgcn_readfirstlane(er[P][0]) >> 27;    // haspad, south, first, last
+    const bool south = (fl & (CLS_SOUTH << 1)) != 0;
+    if ((fl & (CLS_FIRST << 1)) || (south && !prev_south)) {          // first batch of a side: its first member is the origin
+      if (south && north_open) finish_side(sN, qN);
+      north_open = !south;
 #pragma unroll
       for (int f = 0; f < NFLD; ++f) x0[f] = (double)xb[P][0][f];
     }
-    if (flags & OPF_PAD) {                    // a padding entry reads row 0 and weighs nothing
+    prev_south = south;
+    if (fl & 1) {                             // a padding entry reads row 0 and weighs nothing
 #pragma unroll
       for (int j = 0; j < MB; ++j) {
         const double w = er[P][j] < 0 ? 0.0 : 1.0;
@@ -166,7 +165,8 @@ sweep_op_kernel(FieldPtrs<4> fp, int64_t D, int K, const double* __restrict__ yc
       }
       cnt += (double)MB;
     }
-    if (flags & OPF_LAST) {
+    if (fl & (CLS_LAST << 1)) {
+      prev_south = false;
 #pragma unroll
       for (int j = 0; j < YJ; ++j)
         if (lane + 64 * j < YE) yst[lane + 64 * j] = ys[j];
@@ -218,14 +218,12 @@ sweep_op_kernel(FieldPtrs<4> fp, int64_t D, int K, const double* __restrict__ yc
   if (b0 < b1) {
     load_ys(grp);
     // prologue: X of the first PD - 1 batches (the table is padded, a short list just loads padding)
-    rna = coff[((int64_t)b0 * 4 + g) * 2];
-    rnb = coff[((int64_t)b0 * 4 + g) * 2 + 1];
+    rn = crow[(int64_t)b0 * 4 + g];
     static_for<PD - 1>([&](auto kc) __attribute__((always_inline)) {
       constexpr int k = decltype(kc)::value;
-      const longlong2 ra = rna, rb = rnb;
-      rna = coff[((int64_t)(b0 + k + 1) * 4 + g) * 2];
-      rnb = coff[((int64_t)(b0 + k + 1) * 4 + g) * 2 + 1];
-      if (k == 0 || b0 + k < b1) issue(kc, ra, rb);
+      const int4 r0 = rn;
+      rn = crow[(int64_t)(b0 + k + 1) * 4 + g];
+      if (k == 0 || b0 + k < b1) issue(kc, r0);
     });
     for (int b = b0; b < b1; b += PD)
       static_for<PD>([&](auto kc) __attribute__((always_inline)) {

@@ -116,8 +116,6 @@ struct temx_plan {
   int64_t cgroups = 0, cbatches = 0, ncls = 0;
   std::vector<int> gbatch0;            // first batch of every class-group (+ total)
   DevBuf crow, ycls;
-  std::vector<int> crow_host;          // the row table as built (temx_plan_set_tem derives coff from it)
-  DevBuf coff;                         // one-pass sweep 1: 64-bit element offsets row * D + batch flags (kernels_op.hpp)
   std::map<int, DevBuf> csplits;       // work cuts per number of pieces
   Split sp_cproj4, sp_cproj1, sp_ceddy, sp_cflux;
   // one-pass form of the class path: sweep 1 also stores per-class sums of products (csum), the
@@ -528,7 +526,7 @@ struct ClassTables {
 };
 
 static bool build_classes(const double* lat, int64_t N, ClassTables& ct) {
-  if (N >= ((int64_t)1 << 28) || N < 64) return false;
+  if (N >= ((int64_t)1 << 27) || N < 64) return false;     // row indices live in 27 bits of a table entry
   const double tol = sym_tol_deg();
   std::vector<int> order((size_t)N);
   for (int64_t i = 0; i < N; ++i) {
@@ -595,6 +593,8 @@ static bool build_classes(const double* lat, int64_t N, ClassTables& ct) {
         int flags = side ? CLS_SOUTH : 0;
         if (bi == 0 && (side == 0 || bN == 0)) flags |= CLS_FIRST;
         if (bi == nbat - 1 && (side == 1 || bS == 0)) flags |= CLS_LAST;
+        int batch[4 * MB];
+        bool haspad = false;
         for (int k = 0; k < 4; ++k) {
           const int64_t ci = gi * 4 + k;
           for (int j = 0; j < MB; ++j) {
@@ -604,9 +604,11 @@ static bool build_classes(const double* lat, int64_t N, ClassTables& ct) {
               const std::vector<int>& mem = side ? cls[(size_t)ci].s : cls[(size_t)ci].n;
               if (m < mem.size()) ent = mem[m] | (flags << 28);
             }
-            ct.crow.push_back(ent);
+            haspad = haspad || ent < 0;
+            batch[k * MB + j] = ent;
           }
         }
+        for (int e = 0; e < 4 * MB; ++e) ct.crow.push_back(batch[e] | (haspad ? CLS_HASPAD_BIT : 0));
       }
     }
   }
@@ -720,32 +722,6 @@ static int launch_project_cls(temx_plan* pl, const FieldPtrs<NF>& fp, int dtype,
   return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
 }
 
-// one-pass sweep 1 (kernels_op.hpp): the row table as 64-bit element offsets row * D with the batch flags
-static int build_op_table(temx_plan* pl) {
-  const size_t n = pl->crow_host.size();
-  if (n == 0 || n % 16) return fail(TEMX_ESTATE, "no class table");
-  std::vector<int64_t> t(n);
-  bool prev_south = false;
-  for (size_t b = 0; b < n / 16; ++b) {
-    const int fl = (pl->crow_host[b * 16] >> 28) & 7;
-    bool pad = false;
-    for (int e = 0; e < 16; ++e) pad = pad || pl->crow_host[b * 16 + e] < 0;
-    if (fl & CLS_FIRST) prev_south = false;
-    const bool south = (fl & CLS_SOUTH) != 0;
-    int of = (south ? OPF_SOUTH : 0) | ((fl & CLS_LAST) ? OPF_LAST : 0) | (pad ? OPF_PAD : 0);
-    if ((fl & CLS_FIRST) || (south && !prev_south)) of |= OPF_SIDE0;
-    prev_south = south;
-    for (int e = 0; e < 16; ++e) {
-      const int ent = pl->crow_host[b * 16 + e];
-      int64_t v = ent < 0 ? (int64_t)0 : (int64_t)(ent & CLS_ROWMASK) * pl->D;
-      v |= (int64_t)of << 56;
-      if (ent < 0) v |= (int64_t)1 << 63;
-      t[b * 16 + e] = v;
-    }
-  }
-  return upload(pl->coff, t.data(), t.size() * sizeof(int64_t));
-}
-
 template <typename T, int KIND>
 static int launch_sweep_op_t(temx_plan* pl, const FieldPtrs<4>& fp, double* partial, const Split& sp, double* sums,
                              hipStream_t st) {
@@ -756,7 +732,7 @@ static int launch_sweep_op_t(temx_plan* pl, const FieldPtrs<4>& fp, double* part
   constexpr int PDv = KIND == 1 ? (sizeof(T) == 4 ? 4 : 2) : (sizeof(T) == 4 ? TEMX_CLS_OP_PD_F32 : TEMX_CLS_OP_PD);
 #define TEMX_LSO(TBSv)                                                                                \
   hipLaunchKernelGGL((sweep_op_kernel<T, TBSv, PDv, KIND>), grid, block, 0, st, fp, pl->D, pl->K, pl->ycls.d(), \
-                     static_cast<const longlong2*>(pl->coff.p), cuts, pl->colscale.d(), partial, sp.nsplit,  \
+                     static_cast<const int4*>(pl->crow.p), cuts, pl->colscale.d(), partial, sp.nsplit,       \
                      sp.ndt, sums)
   switch (pl->TBS) {
     case 2: TEMX_LSO(2); break;
@@ -1199,7 +1175,6 @@ void temx_plan_destroy(temx_plan* pl) {
                     &pl->Bq, &pl->Bq2, &pl->Ct, &pl->tz, &pl->rows, &pl->ysym, &pl->Bs, &pl->XB, &pl->P3};
   for (DevBuf* b : bufs) b->release();
   pl->crow.release();
-  pl->coff.release();
   pl->ycls.release();
   pl->csum.release();
   pl->ccnt.release();
@@ -1333,7 +1308,7 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
     if ((!pl->large || pl->K <= 256) && !(flags & (TEMX_NO_SYMMETRY | TEMX_NO_CLASSES)) && !(e0 && e0[0] == '1') &&
         !(e1 && e1[0] == '1') && build_classes(lat_deg_host, ncol, ct)) {
       if ((rc = upload(pl->crow, ct.crow.data(), ct.crow.size() * sizeof(int)))) return bail(rc);
-      pl->crow_host = ct.crow;
+
       if ((rc = upload(pl->ccnt, ct.cnt.data(), ct.cnt.size() * 8))) return bail(rc);
       DevBuf xc;
       if ((rc = upload(xc, ct.xc.data(), ct.xc.size() * 8))) return bail(rc);
@@ -1682,7 +1657,6 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
           const size_t need4 = (size_t)std::max(pl->sp_cflux.nsplit * 3, sp_op.nsplit * 7) * pl->K * D * 8;
           if ((rc = pl->partial.ensure(std::max(need4, pl->partial.bytes)))) return rc;
           if ((rc = pl->Pq.ensure((size_t)3 * pl->K * D * 8))) return rc;
-          if ((rc = build_op_table(pl))) return rc;
         }
       }
     }
@@ -1875,9 +1849,10 @@ int temx_tem_stage3(temx_plan* pl, const double* B3, double* results, double* zo
   const int64_t MD = (int64_t)pl->M * pl->D;
   // flux zonal means upvpb upwappb vptpb -> zb[4..6]
   if ((rc = launch_solve(pl, B3, 3, pl->D, nullptr, pl->zb.d() + 4 * MD, st))) return rc;
-  // int_vbdp -> zb[7]: by a wavefront scan for tall columns, inside the epilogue otherwise (one launch fewer)
+  // int_vbdp -> zb[7]: inside the epilogue for small zonal grids (one launch fewer: small shapes pay per
+  // launch), by a wavefront scan otherwise
   EpiTables tb{pl->p.d(), pl->pg.d(), pl->lg.d(), pl->coslat.d(), pl->fcor.d()};
-  if (pl->nlev > 192) {
+  if (pl->nlev > 192 || MD > ((int64_t)1 << 17)) {   // (measured: inline costs 12-25 us extra from 4e5 zonal points up)
     const int64_t ncols = (int64_t)pl->M * pl->nt;
     hipLaunchKernelGGL(pint_scan_kernel, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st, pl->zb.d() + 1 * MD,
                        pl->p.d(), pl->M, pl->nlev, pl->nt, pl->zb.d() + 7 * MD);
@@ -2080,7 +2055,11 @@ int temx_tracer_run(temx_plan* pl, const void* q, const void* va, const void* wa
   int rc = tem_ready(pl);
   if (rc) return rc;
   if ((rc = tracer_ws(pl))) return rc;
-  if (tracer_one_pass(pl)) {     // (q, v, omega) are read once; needs the TEM run's sums of v and omega
+  // The one-pass form reads (q, v, omega) once instead of q + (q, v, omega), but its sweep shares a SIMD
+  // with fewer waves than the two-pass kernels: measured on ne120 x 72 x 30 it is no faster (10.2 ms
+  // against 9.6 ms), so the two-pass stages stay the default and TEMX_TRACER_ONE_PASS=1 selects it.
+  static const bool want_one = [] { const char* e = getenv("TEMX_TRACER_ONE_PASS"); return e && e[0] == '1'; }();
+  if (want_one && tracer_one_pass(pl)) {
     if ((rc = temx_tracer_stage1_sums(pl, q, va, wap, dtype, pl->Bq.d(), stream))) return rc;
     if ((rc = temx_tracer_stage2_from_sums(pl, pl->Bq.d(), pl->Bq2.d(), stream))) return rc;
     return temx_tracer_stage3(pl, pl->Bq2.d(), tres, tzon, stream);

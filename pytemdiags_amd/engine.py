@@ -59,6 +59,13 @@ class Plan:
         """True when (after ``set_tem``) the class path reads the fields once (see include/temx.h)."""
         return bool(self.lib.temx_plan_one_pass(self._h))
 
+    @property
+    def tracer_one_pass(self):
+        """True when tracer runs should take the one-pass stages (``one_pass`` and TEMX_TRACER_ONE_PASS=1;
+        the two-pass tracer stages measured faster, see include/temx.h)."""
+        import os
+        return self.one_pass and os.environ.get("TEMX_TRACER_ONE_PASS") == "1"
+
     # ---- lifetime ----
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

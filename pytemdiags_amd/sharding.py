@@ -96,7 +96,7 @@ class NcolShardedTEM:
         """Tracer TEM for one tracer; call after ``run`` on the same fields (two more all-reduces:
         [K][D] sums of q, [2][K][D] sums of q'v', q'w')."""
         be = self.backend
-        if getattr(be, "one_pass", False):             # (q, v, omega) read once, see include/temx.h
+        if getattr(be, "tracer_one_pass", False):      # (q, v, omega) read once, see include/temx.h
             Bq = be.tracer_stage1_sums(q, va, wap)
             allreduce_sum_(Bq, self.group)
             Bq2 = be.tracer_stage2_from_sums(Bq)

@@ -33,7 +33,7 @@ with open("profiles/%s_pmc_counters_ne120x72x30.csv" % rnd, "w") as fh:
     for r in sorted(out):
         fh.write("\"%s\",%s,%d,%.6g\n" % r)
 e = [k for k, _ in tot if ("eddy" in k and "kernel<double" in k) or "flux_cls_kernel" in k][0]
-p = [k for k, _ in tot if "project" in k and "kernel<double, 4" in k][0]
+p = [k for k, _ in tot if ("project" in k and "kernel<double, 4" in k) or "sweep_op_kernel<double" in k][0]
 mode = "latitude-class, one pass" if "flux_cls" in e else "latitude-class" if "_cls_" in e else ("mirror-paired" if "_sym_" in e else "generic")
 tr = {"workload": "ne120x72x30", "dtype": "f64", "sweeps": mode,
       "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB per dispatch; FETCH_SIZE doubled per "

@@ -4,7 +4,7 @@
 # writes bench JSON lines, the rocprofv3 kernel-trace summary and three PMC passes under gpurun_out/;
 # tools/collect_profiles.py stats_<round> pmc_<round> <round>  then copies the summaries into profiles/.
 set -eo pipefail
-R=${1:-r01}
+R=${1:-r02}
 REPO=$PWD
 O=$REPO/gpurun_out
 mkdir -p "$O"
