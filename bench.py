@@ -275,8 +275,8 @@ def main():
         if plan.one_pass and nproj:
             # one-pass class path: the dominant kernel is sweep 1 (the only read of the fields)
             gbs_p = 4 * esize * pts_rank / (proj_ms * 1e-3) / 1e9
-            rec["roofline"] = {"kernel": "project_cls_kernel, one-pass form (theta + class sums of the fields, centred "
-                                         "class co-moments of u v, u omega, v theta + 7 class projections)",
+            rec["roofline"] = {"kernel": "sweep_op_kernel (sweep 1 of the one-pass class path: theta + class sums of the fields, "
+                                         "centred class co-moments of u v, u omega, v theta + 7 class projections)",
                                "bound": "hbm", "achieved": gbs_p, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": gbs_p / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": proj_ms,
                                "launches": nproj,
