@@ -244,214 +244,6 @@ sweep_op_kernel(FieldPtrs<4> fp, int64_t D, int K, const double* __restrict__ yc
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// sweep_pair_kernel: sweep 1 of the one-pass class path with TWO waves per SIMD.  sweep_op_kernel's 98
-// accumulators leave room for one wave per SIMD, and that single in-order instruction stream -- not the
-// HBM traffic -- is what holds it at 4.4-4.8 TB/s.  Here two waves share a d-tile: one
-// walks the northern member rows of every class-group, the other the southern ones (per-side row
-// tables crow2, every group has at least one batch per side).  When a group is complete they exchange
-// their 4 sums + 3 co-moments through LDS (one workgroup barrier per group, double buffered) and the
-// northern wave projects N + S onto the even harmonics, the southern wave N - S onto the odd ones:
-// 49 accumulators each, 8 waves per CU.  Records, partial slabs and results are those of sweep_op_kernel.
-// ------------------------------------------------------------------------------------------------
-template <typename T, int TBS, int PD>
-__global__ void __launch_bounds__(512, 1)
-sweep_pair_kernel(FieldPtrs<4> fp, int64_t D, int K, const double* __restrict__ ycls,
-                  const int4* __restrict__ crowN, const int4* __restrict__ crowS,
-                  const int* __restrict__ gfirstN, const int* __restrict__ gfirstS /* [groups + 1] first batch of a group in the side's table */,
-                  const int2* __restrict__ csplit /* .y = first group of a piece */, const double* __restrict__ colscale,
-                  double* __restrict__ partial, int nsplit, int ndt, double* __restrict__ csum) {
-  constexpr int YE = TBS * 16;                // this wave's half of the group's Y blocks (even or odd harmonics)
-  constexpr int YJ = (YE + 63) / 64;
-  constexpr int MB = CLS_MB;
-  constexpr int NA = 7;
-  static_assert(MB == 4 && PD + 1 <= CLS_PADB, "table layout");
-  __shared__ double ystage[8][YE];            // wave private
-  __shared__ double xch[2][4][2][NA][64];     // [group parity][d-tile][side][sum][lane]
-  int split, dq;
-  if (!wg_work((ndt + 3) / 4, nsplit, split, dq)) return;      // (uniform per workgroup)
-  const int wave = uniform_wave(), lane = threadIdx.x & 63;
-  const int side = wave >> 2, tile = wave & 3;
-  const int c = lane & 15, g = lane >> 4;
-  int dt = dq * 4 + tile;
-  const bool tvalid = dt < ndt;               // a ragged last quad: the spare waves walk the last tile again (barriers)
-  if (!tvalid) dt = ndt - 1;
-  const int64_t d = (int64_t)dt * 16 + c;
-  const bool dvalid = tvalid && d < D;
-  const int64_t dcl = d < D ? d : D - 1;
-  const int g0 = __builtin_amdgcn_readfirstlane(csplit[split].y);
-  const int g1 = __builtin_amdgcn_readfirstlane(csplit[split + 1].y);
-  const int4* __restrict__ crow = side ? crowS : crowN;
-  const int* __restrict__ gfirst = side ? gfirstS : gfirstN;
-  const int b0 = __builtin_amdgcn_readfirstlane(gfirst[g0]);
-  const int b1 = __builtin_amdgcn_readfirstlane(gfirst[g1]);
-  int grp = g0;
-  const uint32_t yoff = (uint32_t)(g * 4 + (lane & 3));
-  double* yst = ystage[wave];
-  const double sth = colscale != nullptr ? colscale[dcl] : 1.0;
-  const uint32_t D32 = (uint32_t)D;
-  const T* fb[4];
-#pragma unroll
-  for (int f = 0; f < 4; ++f) fb[f] = reinterpret_cast<const T*>(fp.p[f]) + dcl;
-
-  double acc[NA][TBS];
-#pragma unroll
-  for (int f = 0; f < NA; ++f)
-#pragma unroll
-    for (int t = 0; t < TBS; ++t) acc[f][t] = 0.0;
-  double s[4] = {0.0, 0.0, 0.0, 0.0}, q[3] = {0.0, 0.0, 0.0}, x0[4] = {0.0, 0.0, 0.0, 0.0}, cnt = 0.0;
-
-  T xb[PD][MB][4];
-  int er[PD][MB];
-  double ys[YJ];
-  auto load_ys = [&](int gi) __attribute__((always_inline)) {     // blocks [side * TBS, side * TBS + TBS) of the group
-#pragma unroll
-    for (int j = 0; j < YJ; ++j)
-      ys[j] = (ycls + ((int64_t)gi * 2 + side) * YE)[(lane + 64 * j) < YE ? (lane + 64 * j) : 0];
-  };
-  auto issue = [&](auto pc, const int4 rv) __attribute__((always_inline)) {
-    constexpr int P = decltype(pc)::value;
-    er[P][0] = rv.x; er[P][1] = rv.y; er[P][2] = rv.z; er[P][3] = rv.w;
-#pragma unroll
-    for (int j = 0; j < MB; ++j) {
-      const uint64_t off = (uint64_t)(uint32_t)(er[P][j] & CLS_ROWMASK) * D32;
-#pragma unroll
-      for (int f = 0; f < 4; ++f) xb[P][j][f] = TEMX_XLOAD(fb[f] + off);
-      __builtin_amdgcn_sched_barrier(0);      // one row's addresses at a time: 256 registers are all this wave has
-    }
-  };
-  int4 rn;
-  auto step = [&](auto pc, int b) __attribute__((always_inline)) {
-    constexpr int P = decltype(pc)::value;
-    if (b + (PD - 1) < b1) {                  // index load first: it must not queue behind the X loads
-      const int4 r1 = rn;
-      rn = crow[(int64_t)(b + PD) * 4 + g];
-      issue(std::integral_constant<int, (P + PD - 1) % PD>{}, r1);
-    }
-    const int fl = __builtin_amdgcn_readfirstlane(er[P][0]) >> 27;    // haspad, -, first, last (of this side in the group)
-    if (fl & (CLS_FIRST << 1)) {              // the side's first member is the origin of its sums
-#pragma unroll
-      for (int f = 0; f < 4; ++f) x0[f] = (double)xb[P][0][f];
-    }
-    if (fl & 1) {                             // a padding entry reads row 0 and weighs nothing
-#pragma unroll
-      for (int j = 0; j < MB; ++j) {
-        const double w = er[P][j] < 0 ? 0.0 : 1.0;
-        const double du = (double)xb[P][j][0] - x0[0], dv = (double)xb[P][j][1] - x0[1];
-        const double dth = (double)xb[P][j][2] - x0[2], dw = (double)xb[P][j][3] - x0[3];
-        const double u = w * du, v = w * dv;
-        s[0] += u;
-        s[1] += v;
-        s[2] += w * dth;
-        s[3] += w * dw;
-        q[0] += u * dv;
-        q[1] += u * dw;
-        q[2] += v * dth;
-        cnt += w;
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < MB; ++j) {
-        const double du = (double)xb[P][j][0] - x0[0], dv = (double)xb[P][j][1] - x0[1];
-        const double dth = (double)xb[P][j][2] - x0[2], dw = (double)xb[P][j][3] - x0[3];
-        s[0] += du;
-        s[1] += dv;
-        s[2] += dth;
-        s[3] += dw;
-        q[0] += du * dv;
-        q[1] += du * dw;
-        q[2] += dv * dth;
-        __builtin_amdgcn_sched_barrier(0);    // one member row at a time (register budget)
-      }
-      cnt += (double)MB;
-    }
-    if (fl & (CLS_LAST << 1)) {               // this side of the group is complete
-#pragma unroll
-      for (int j = 0; j < YJ; ++j)
-        if (lane + 64 * j < YE) yst[lane + 64 * j] = ys[j];
-      // shifted sums -> true sums and centred co-moments (theta-scaled), in place: s[0..3], q[0..2]
-      {
-        const double rn_ = cnt > 0.0 ? 1.0 / cnt : 0.0;
-        q[0] -= s[0] * s[1] * rn_;
-        q[1] -= s[0] * s[3] * rn_;
-        q[2] = (q[2] - s[1] * s[2] * rn_) * sth;
-#pragma unroll
-        for (int f = 0; f < 4; ++f) s[f] += cnt * x0[f];
-        s[2] *= sth;
-        cnt = 0.0;
-      }
-      const int buf = grp & 1;
-      double* mx = &xch[buf][tile][side][0][lane];          // handed to the partner wave
-      const double* ox = &xch[buf][tile][side ^ 1][0][lane];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) mx[k * 64] = s[k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) mx[(4 + k) * 64] = q[k];
-      __syncthreads();                        // every wave of the workgroup ends the same groups: same barrier count
-      if (dvalid) {                           // the record {north, south}: each wave stores two of the four fields
-        double2* o = reinterpret_cast<double2*>(csum + (((int64_t)grp * ndt + dt) * 8) * 64) + lane;
-        const int f0 = side * 2;
-        const double o0 = ox[f0 * 64], o1 = ox[(f0 + 1) * 64];
-        const double m0 = side ? s[2] : s[0], m1 = side ? s[3] : s[1];
-        TEMX_CSTORE(o + f0 * 64, side ? make_double2(o0, m0) : make_double2(m0, o0));
-        TEMX_CSTORE(o + (f0 + 1) * 64, side ? make_double2(o1, m1) : make_double2(m1, o1));
-      }
-      // north: N + S (feeds the even harmonics); south: N - S (the odd ones) -- in place
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const double o = ox[k * 64];
-        s[k] = side ? o - s[k] : s[k] + o;
-      }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const double o = ox[(4 + k) * 64];
-        q[k] = side ? o - q[k] : q[k] + o;
-      }
-      ++grp;
-      load_ys(grp);                           // ycls is padded by one group
-#pragma unroll
-      for (int t = 0; t < TBS; ++t) {
-        const double ya = yst[t * 16 + yoff];
-#pragma unroll
-        for (int f = 0; f < 4; ++f) acc[f][t] = TEMX_MFMA4(ya, s[f], acc[f][t]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) acc[4 + k][t] = TEMX_MFMA4(ya, q[k], acc[4 + k][t]);
-      }
-#pragma unroll
-      for (int f = 0; f < 4; ++f) s[f] = 0.0;
-      q[0] = q[1] = q[2] = 0.0;
-    }
-  };
-
-  if (b0 < b1) {
-    load_ys(grp);
-    rn = crow[(int64_t)b0 * 4 + g];
-    static_for<PD - 1>([&](auto kc) __attribute__((always_inline)) {
-      constexpr int k = decltype(kc)::value;
-      const int4 r0 = rn;
-      rn = crow[(int64_t)(b0 + k + 1) * 4 + g];
-      if (k == 0 || b0 + k < b1) issue(kc, r0);
-    });
-    for (int b = b0; b < b1; b += PD)
-      static_for<PD>([&](auto kc) __attribute__((always_inline)) {
-        constexpr int k = decltype(kc)::value;
-        if (k == 0 || b + k < b1) step(kc, b + k);
-      });
-  }
-
-  // (an empty range still stores its zero slab: the reduction sums every slab)
-  if (dvalid) {
-#pragma unroll
-    for (int f = 0; f < NA; ++f)
-#pragma unroll
-      for (int t = 0; t < TBS; ++t) {
-        const int l = sym_harm<TBS>(side * TBS + t, g);
-        if (l < K) partial[(((int64_t)split * NA + f) * K + l) * D + d] = acc[f][t];
-      }
-  }
-}
-
 // Tried and measured, not kept (round 2): the same sweep with 16-byte loads -- a lane loading 2 (fp64) or
 // 4 (fp32) adjacent columns of 8 or 16 member rows per instruction, the partial sums of the lanes that
 // share a class added and transposed into the MFMA operand layout through wave-private LDS.  A bare
@@ -462,5 +254,13 @@ sweep_pair_kernel(FieldPtrs<4> fp, int64_t D, int K, const double* __restrict__ 
 // other through LDS without a workgroup barrier need a compiler barrier -- asm volatile("" ::: "memory")
 // -- between the writes and the reads, or the reads of other lanes' values are hoisted above the writes;
 // a C++ fence at wavefront scope is also correct but drains the global loads in flight.)
+//
+// Also tried and measured, not kept: two waves per SIMD by pairing waves on a d-tile -- one wave walks the
+// northern member rows of every class-group, the other the southern ones (per-hemisphere row tables),
+// they exchange their 4 sums + 3 co-moments through LDS behind one workgroup barrier per class-group,
+// and the northern wave projects N + S onto the even harmonics, the southern N - S onto the odd ones
+// (49 accumulators each).  Correct (parity 1.2e-13), but 18.4 ms against 11.3 ms on ne120 x 72 x 30 and
+// 3.5 ms against 1.8 ms on ne240 x 128 x 1 fp32: a barrier every two batches phase-locks all eight waves
+// of the CU, and 256 registers per wave still spill the loop invariants.
 
 }  // namespace temx

@@ -116,7 +116,6 @@ struct temx_plan {
   int64_t cgroups = 0, cbatches = 0, ncls = 0;
   std::vector<int> gbatch0;            // first batch of every class-group (+ total)
   DevBuf crow, ycls;
-  DevBuf crow2[2], gfirst2[2];         // per-hemisphere row tables of sweep_pair_kernel
   std::map<int, DevBuf> csplits;       // work cuts per number of pieces
   Split sp_cproj4, sp_cproj1, sp_ceddy, sp_cflux;
   // one-pass form of the class path: sweep 1 also stores per-class sums of products (csum), the
@@ -523,10 +522,6 @@ struct ClassTables {
   std::vector<double> xc;       // [4 * (ngroups + 1)] cos(colat) of the class latitude
   std::vector<int> gbatch0;     // [ngroups + 1]
   std::vector<double> cnt;      // [ngroups][2 sides][4 classes] member counts
-  // per-side tables of the wave-pair sweep (sweep_pair_kernel): the batches of one hemisphere only, group
-  // after group, every group with at least one batch (an all-padding one where the side is empty);
-  // FIRST / LAST flag the side's first / last batch of a group; gfirst2[side][g] = first batch of group g
-  std::vector<int> crow2[2], gfirst2[2];
   int64_t ncls = 0, ngroups = 0, nbatch = 0;
 };
 
@@ -579,10 +574,6 @@ static bool build_classes(const double* lat, int64_t N, ClassTables& ct) {
   ct.gbatch0.assign((size_t)ct.ngroups + 1, 0);
   ct.cnt.assign((size_t)ct.ngroups * 8, 0.0);
   ct.crow.clear();
-  for (int side = 0; side < 2; ++side) {
-    ct.crow2[side].clear();
-    ct.gfirst2[side].clear();
-  }
   const double d2r = M_PI / 180.0;
   for (int64_t gi = 0; gi < ct.ngroups; ++gi) {
     int bN = 0, bS = 0;
@@ -596,30 +587,6 @@ static bool build_classes(const double* lat, int64_t N, ClassTables& ct) {
       ct.cnt[(size_t)gi * 8 + 4 + k] = (double)cls[(size_t)ci].s.size();
     }
     ct.gbatch0[(size_t)gi] = (int)(ct.crow.size() / (4 * MB));
-    for (int side = 0; side < 2; ++side) {      // the same rows, one table per hemisphere
-      std::vector<int>& t2 = ct.crow2[side];
-      ct.gfirst2[side].push_back((int)(t2.size() / (4 * MB)));
-      const int nb2 = std::max(1, side ? bS : bN);
-      for (int bi = 0; bi < nb2; ++bi) {
-        const int flags = (bi == 0 ? CLS_FIRST : 0) | (bi == nb2 - 1 ? CLS_LAST : 0);
-        int batch[4 * MB];
-        bool haspad = false;
-        for (int k = 0; k < 4; ++k) {
-          const int64_t ci = gi * 4 + k;
-          for (int j = 0; j < MB; ++j) {
-            const size_t m = (size_t)bi * MB + j;
-            int ent = (int)0x80000000 | (flags << 28);
-            if (ci < ct.ncls) {
-              const std::vector<int>& mem = side ? cls[(size_t)ci].s : cls[(size_t)ci].n;
-              if (m < mem.size()) ent = mem[m] | (flags << 28);
-            }
-            haspad = haspad || ent < 0;
-            batch[k * MB + j] = ent;
-          }
-        }
-        for (int e = 0; e < 4 * MB; ++e) t2.push_back(batch[e] | (haspad ? CLS_HASPAD_BIT : 0));
-      }
-    }
     for (int side = 0; side < 2; ++side) {
       const int nbat = side ? bS : bN;
       for (int bi = 0; bi < nbat; ++bi) {
@@ -648,10 +615,6 @@ static bool build_classes(const double* lat, int64_t N, ClassTables& ct) {
   ct.nbatch = (int64_t)(ct.crow.size() / (4 * MB));
   ct.gbatch0[(size_t)ct.ngroups] = (int)ct.nbatch;
   ct.crow.resize(ct.crow.size() + (size_t)CLS_PADB * 4 * MB, (int)0x80000000);   // index loads run ahead
-  for (int side = 0; side < 2; ++side) {
-    ct.gfirst2[side].push_back((int)(ct.crow2[side].size() / (4 * MB)));
-    ct.crow2[side].resize(ct.crow2[side].size() + (size_t)CLS_PADB * 4 * MB, (int)0x80000000);
-  }
   return true;
 }
 
@@ -782,46 +745,10 @@ static int launch_sweep_op_t(temx_plan* pl, const FieldPtrs<4>& fp, double* part
   return TEMX_OK;
 }
 
-#ifndef TEMX_PAIR_PD
-#define TEMX_PAIR_PD 2
-#endif
-#ifndef TEMX_PAIR_PD_F32
-#define TEMX_PAIR_PD_F32 3
-#endif
-// the same sweep with two waves per SIMD: one wave per hemisphere of a d-tile (sweep_pair_kernel)
-template <typename T>
-static int launch_sweep_pair_t(temx_plan* pl, const FieldPtrs<4>& fp, double* partial, const Split& sp, hipStream_t st) {
-  const int2* cuts = nullptr;
-  if (int rc = class_cuts(pl, sp.nsplit, &cuts, true)) return rc;
-  dim3 grid(sp.grid), block(512);
-  constexpr int PDv = sizeof(T) == 4 ? TEMX_PAIR_PD_F32 : TEMX_PAIR_PD;
-#define TEMX_LSP2(TBSv)                                                                               \
-  hipLaunchKernelGGL((sweep_pair_kernel<T, TBSv, PDv>), grid, block, 0, st, fp, pl->D, pl->K, pl->ycls.d(),     \
-                     static_cast<const int4*>(pl->crow2[0].p), static_cast<const int4*>(pl->crow2[1].p),       \
-                     static_cast<const int*>(pl->gfirst2[0].p), static_cast<const int*>(pl->gfirst2[1].p), cuts, \
-                     pl->colscale.d(), partial, sp.nsplit, sp.ndt, pl->csum.d())
-  switch (pl->TBS) {
-    case 2: TEMX_LSP2(2); break;
-    case 4: TEMX_LSP2(4); break;
-    case 7: TEMX_LSP2(7); break;
-    default: TEMX_LSP2(8); break;
-  }
-#undef TEMX_LSP2
-  HIPCHK(hipGetLastError());
-  return TEMX_OK;
-}
-
 // KIND 0: (u, v, T, omega) -> csum; KIND 1: (q, v, omega) -> csq
 template <int KIND>
 static int launch_sweep_op(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, double* partial, const Split& sp,
                            hipStream_t st) {
-  if constexpr (KIND == 0) {
-    static const bool pair = [] { const char* e = getenv("TEMX_OP_PAIR"); return e && e[0] == '1'; }();
-    if (pair) {
-      if (dtype == TEMX_F64) return launch_sweep_pair_t<double>(pl, fp, partial, sp, st);
-      if (dtype == TEMX_F32) return launch_sweep_pair_t<float>(pl, fp, partial, sp, st);
-    }
-  }
   double* sums = KIND == 0 ? pl->csum.d() : pl->csq.d();
   if (dtype == TEMX_F64) return launch_sweep_op_t<double, KIND>(pl, fp, partial, sp, sums, st);
   if (dtype == TEMX_F32) return launch_sweep_op_t<float, KIND>(pl, fp, partial, sp, sums, st);
@@ -1248,10 +1175,6 @@ void temx_plan_destroy(temx_plan* pl) {
                     &pl->Bq, &pl->Bq2, &pl->Ct, &pl->tz, &pl->rows, &pl->ysym, &pl->Bs, &pl->XB, &pl->P3};
   for (DevBuf* b : bufs) b->release();
   pl->crow.release();
-  for (int sd = 0; sd < 2; ++sd) {
-    pl->crow2[sd].release();
-    pl->gfirst2[sd].release();
-  }
   pl->ycls.release();
   pl->csum.release();
   pl->ccnt.release();
@@ -1385,10 +1308,6 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
     if ((!pl->large || pl->K <= 256) && !(flags & (TEMX_NO_SYMMETRY | TEMX_NO_CLASSES)) && !(e0 && e0[0] == '1') &&
         !(e1 && e1[0] == '1') && build_classes(lat_deg_host, ncol, ct)) {
       if ((rc = upload(pl->crow, ct.crow.data(), ct.crow.size() * sizeof(int)))) return bail(rc);
-      for (int sd = 0; sd < 2; ++sd) {
-        if ((rc = upload(pl->crow2[sd], ct.crow2[sd].data(), ct.crow2[sd].size() * sizeof(int)))) return bail(rc);
-        if ((rc = upload(pl->gfirst2[sd], ct.gfirst2[sd].data(), ct.gfirst2[sd].size() * sizeof(int)))) return bail(rc);
-      }
 
       if ((rc = upload(pl->ccnt, ct.cnt.data(), ct.cnt.size() * 8))) return bail(rc);
       DevBuf xc;
