@@ -90,6 +90,33 @@ class OracleBackend:
         return self.tem_stage3(self.tem_stage2(ua, va, ta, wap, B4), want_zonal)
 
 
+class OnePassOracleBackend(OracleBackend):
+    """The same stand-in with the one-pass stage interface of engine.Plan: stage 1 leaves state (the
+    engine: per-class sums) that the from-sums stages consume without being handed the fields again."""
+    one_pass = True
+    tracer_one_pass = True
+
+    def tem_stage1(self, ua, va, ta, wap):
+        self._kept = (ua, va, ta, wap)
+        return super().tem_stage1(ua, va, ta, wap)
+
+    def tem_stage2(self, *a):
+        raise AssertionError("the driver must use tem_stage2_from_sums on a one-pass backend")
+
+    def tem_stage2_from_sums(self, B4):
+        return OracleBackend.tem_stage2(self, *self._kept, B4)
+
+    def tracer_stage1(self, q):
+        raise AssertionError("the driver must use tracer_stage1_sums on a one-pass backend")
+
+    def tracer_stage1_sums(self, q, va, wap):
+        self._kept_q = (q, va, wap)
+        return OracleBackend.tracer_stage1(self, q)
+
+    def tracer_stage2_from_sums(self, Bq):
+        return OracleBackend.tracer_stage2(self, *self._kept_q, Bq)
+
+
 _LON = synth.cubed_sphere_gll(NE)[1]
 
 
@@ -107,9 +134,9 @@ def _worker(rank, world, port, mode, ret):
     try:
         lat, plev, f = _data()
         lat_zm = orc.zm_latitudes(1)
-        if mode == "ncol":
+        if mode in ("ncol", "ncol-one-pass"):
             i0, i1 = sharding.shard_bounds(lat.size, world, rank)
-            be = OracleBackend(lat[i0:i1], lat_zm, L, plev)
+            be = (OracleBackend if mode == "ncol" else OnePassOracleBackend)(lat[i0:i1], lat_zm, L, plev)
             runner = sharding.NcolShardedTEM(be)
             res, _ = runner.run(*[x[i0:i1] for x in f])
             q = synth.analytic_tracer(lat, _LON, plev, NT)
@@ -136,7 +163,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("mode", ["ncol", "time"])
+@pytest.mark.parametrize("mode", ["ncol", "ncol-one-pass", "time"])
 def test_sharded_pipeline_world2_gloo(mode):
     lat, plev, f = _data()
     q = synth.analytic_tracer(lat, _LON, plev, NT)
@@ -151,12 +178,12 @@ def test_sharded_pipeline_world2_gloo(mode):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert got.shape == ((16 if mode == "ncol" else 10), 180, NLEV, NT)
+    assert got.shape == ((16 if mode.startswith("ncol") else 10), 180, NLEV, NT)
     for i, n in enumerate(orc.RESULTS):
         r = getattr(ref, n)()
         err = np.max(np.abs(got[i] - r)) / np.max(np.abs(r))
         assert err <= 1e-10, (mode, n, err)
-    if mode == "ncol":      # tracer TEM through the sharded driver (two more all-reduces)
+    if mode.startswith("ncol"):      # tracer TEM through the sharded driver (two more all-reduces)
         for i, n in enumerate(orc.TRACER_RESULTS):
             r = getattr(ref, n)(0)
             err = np.max(np.abs(got[10 + i] - r)) / np.max(np.abs(r))
