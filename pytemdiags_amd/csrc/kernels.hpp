@@ -769,8 +769,9 @@ pint_scan_kernel(const double* __restrict__ vb, const double* __restrict__ p, in
 // (all L1/L2 resident), so the ten GM16 Table-A1 outputs come out of a single launch.
 // zb: [8][M][D] = ub vb thetab wapb upvpb upwappb vptpb int_vbdp.
 // INLINE_INT: int_vbdp (the cumulative trapezoid of vb from the model top, tem_util.py:230-232) is summed
-// by the thread itself -- O(nlev) L1/L2 reads per point, one launch fewer than pint_scan_kernel (it is the
-// launches, 4-8 us each, that small shapes pay for) -- and stored to zb[7] for later readers.
+// by the thread itself -- O(nlev) L1/L2 reads per point instead of a launch of pint_scan_kernel -- and
+// stored to zb[7] for later readers.  Pays for short columns only (the host decides): measured on
+// ne30 x 72 x 1 the loop costs the 5 us the launch saves, on nlev = 128 more.
 template <bool INLINE_INT>
 __global__ void __launch_bounds__(256)
 tem_epilogue_kernel(double* __restrict__ zb, int M, int nlev, int64_t nt, EpiTables tb,

@@ -1849,10 +1849,10 @@ int temx_tem_stage3(temx_plan* pl, const double* B3, double* results, double* zo
   const int64_t MD = (int64_t)pl->M * pl->D;
   // flux zonal means upvpb upwappb vptpb -> zb[4..6]
   if ((rc = launch_solve(pl, B3, 3, pl->D, nullptr, pl->zb.d() + 4 * MD, st))) return rc;
-  // int_vbdp -> zb[7]: inside the epilogue for small zonal grids (one launch fewer: small shapes pay per
-  // launch), by a wavefront scan otherwise
+  // int_vbdp -> zb[7]: by a wavefront scan; inside the epilogue only for short columns on small zonal grids
+  // (measured: at nlev = 72 the O(nlev) loop per point costs what the extra launch saves, at 128 more)
   EpiTables tb{pl->p.d(), pl->pg.d(), pl->lg.d(), pl->coslat.d(), pl->fcor.d()};
-  if (pl->nlev > 192 || MD > ((int64_t)1 << 17)) {   // (measured: inline costs 12-25 us extra from 4e5 zonal points up)
+  if (pl->nlev > 40 || MD > ((int64_t)1 << 17)) {
     const int64_t ncols = (int64_t)pl->M * pl->nt;
     hipLaunchKernelGGL(pint_scan_kernel, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st, pl->zb.d() + 1 * MD,
                        pl->p.d(), pl->M, pl->nlev, pl->nt, pl->zb.d() + 7 * MD);
