@@ -194,3 +194,20 @@ def test_map_cache_file_format_host(tmp_path):
     assert np.array_equal(d["Y0"][1], Y0) and np.array_equal(d["Y0inv"][1], Y0inv)
     with open(p, "rb") as fh:
         assert fh.read(3) == b"CDF"
+
+
+def test_bench_self_launches_one_rank_per_gpu():
+    """`python bench.py --gpus 2` without a launcher starts torch.distributed.run itself (before anything
+    touches a GPU) and returns the child's exit code.  Without a GPU every rank stops with the
+    no-fallback message, so the exit code is non-zero -- which is what this checks, on CPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""                 # also on a GPU box: the ranks must not find a device
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--also", ""], capture_output=True, text=True, timeout=300, env=env)
+    out = p.stdout + p.stderr
+    assert p.returncode != 0, out[-2000:]
+    assert out.count("bench.py needs a GPU") >= 2, out[-2000:]      # one message per rank: two ranks were started
