@@ -41,19 +41,17 @@
 
 namespace temx {
 
-// X is read once per sweep.  Non-temporal loads (-DTEMX_NT_LOADS) were measured: +2 % on ne120x72x30
-// (6.0 TB/s) but -20 % on the ne30 shapes, so plain loads stay the default.
+// X is read once per sweep.  Non-temporal loads (-DTEMX_NT_LOADS) were measured: round 1 +2 % on
+// ne120x72x30 for the two-pass sweeps but -20 % on the ne30 shapes; round 2, one-pass sweep: +-0 on
+// ne120x72x30, -26 % on ne30x72x91 and on ne240x128x1 fp32.  Plain loads stay the default.  (A 4-deep X
+// ring in the one-pass sweep, -DTEMX_CLS_OP_PD=4, measured +-0 as well.)
 #ifdef TEMX_NT_LOADS
 #define TEMX_XLOAD(p) __builtin_nontemporal_load(p)
 #else
 #define TEMX_XLOAD(p) (*(p))
 #endif
 
-#ifdef TEMX_NT_CSUM
-#define TEMX_CSTORE(p, v) __builtin_nontemporal_store((v), (p))
-#else
 #define TEMX_CSTORE(p, v) (*(p) = (v))
-#endif
 
 constexpr int CLS_MB = 4;                     // member rows per class and batch
 constexpr int CLS_PADB = 10;                  // batches of padding behind crow (index loads run up to PD + 1 ahead)
