@@ -262,5 +262,10 @@ sweep_op_kernel(FieldPtrs<4> fp, int64_t D, int K, const double* __restrict__ yc
 // (49 accumulators each).  Correct (parity 1.2e-13), but 18.4 ms against 11.3 ms on ne120 x 72 x 30 and
 // 3.5 ms against 1.8 ms on ne240 x 128 x 1 fp32: a barrier every two batches phase-locks all eight waves
 // of the CU, and 256 registers per wave still spill the loop invariants.
+//
+// And: two INDEPENDENT waves per SIMD by letting a wave cover 8 of a d-tile's 16 columns, the four blocks
+// of the 4x4x4 MFMA used as 2 column-blocks x 2 harmonic-blocks (49 accumulators, 248 registers, no spill,
+// no exchange between waves beyond one lane-swap per class side).  Correct (1.3e-13), but the member rows
+// are then read as 64-byte pieces: 17.6 ms against 10.8 ms on ne120 x 72 x 30 (3.0 TB/s).
 
 }  // namespace temx
