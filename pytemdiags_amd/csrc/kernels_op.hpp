@@ -185,7 +185,7 @@ sweep_op_kernel(FieldPtrs<4> fp, int64_t D, int K, const double* __restrict__ yc
         qN[NQ - 1] *= sth; qS[NQ - 1] *= sth;
       }
       if (dvalid) {                           // record row f = {northern, southern} sum of field f per lane
-        double2* o = reinterpret_cast<double2*>(csum + (((int64_t)grp * ndt + dt) * (2 * NST)) * 64) + lane;
+        double2* o = reinterpret_cast<double2*>(csum + TEMX_CSUM_REC(grp, dt, ndt) * (2 * NST) * 64) + lane;
 #pragma unroll
         for (int f = 0; f < NST; ++f) TEMX_CSTORE(o + f * 64, make_double2(sN[f], sS[f]));
       }
