@@ -51,19 +51,15 @@ namespace temx {
 #define TEMX_XLOAD(p) (*(p))
 #endif
 
-// class-sum record stores; the lab builds (tools/sweep_lab.hip) swap them for nothing / non-temporal stores
+// class-sum record stores.  The records are written once and read by a later kernel; measured on ne120 x
+// 72 x 30 (tools/sweep_lab.hip, profiles/r03_lab_*.log): non-temporal stores 10.9-11.1 ms whatever the
+// placement of the buffer, plain stores 10.9-11.1 / 11.5-11.9 ms (fast / slow placement, see
+// alloc_write_stream in temx.hip), sc0 sc1 stores 10.9-11.0 / 11.2-11.6 ms.  The lab builds swap flavours.
 typedef double temx_d2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void temx_nt_store2(double2* p, double2 v) {
   temx_d2v t = {v.x, v.y};
   __builtin_nontemporal_store(t, reinterpret_cast<temx_d2v*>(p));
 }
-// index of the class-sum record of (class-group, d-tile); lab builds try other layouts
-#ifdef TEMX_LAB
-__device__ int64_t temx_lab_ngr;
-#endif
-#ifndef TEMX_CSUM_REC
-#define TEMX_CSUM_REC(grp, dt, ndt) ((int64_t)(grp) * (ndt) + (dt))
-#endif
 __device__ __forceinline__ void temx_sc1_store2(double2* p, double2 v) {
   temx_d2v t = {v.x, v.y};
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(t) : "memory");
@@ -72,10 +68,17 @@ __device__ __forceinline__ void temx_sc1_store2(double2* p, double2 v) {
 #define TEMX_CSTORE(p, v) ((void)(p), (void)(v))
 #elif defined(TEMX_CSTORE_SC1)       // write-through, the line is dropped from L2
 #define TEMX_CSTORE(p, v) temx_sc1_store2((p), (v))
-#elif defined(TEMX_CSTORE_NT)
-#define TEMX_CSTORE(p, v) temx_nt_store2((p), (v))
-#else
+#elif defined(TEMX_CSTORE_PLAIN)
 #define TEMX_CSTORE(p, v) (*(p) = (v))
+#else
+#define TEMX_CSTORE(p, v) temx_nt_store2((p), (v))
+#endif
+// index of the class-sum record of (class-group, d-tile); lab builds try other layouts
+#ifdef TEMX_LAB
+__device__ int64_t temx_lab_ngr;
+#endif
+#ifndef TEMX_CSUM_REC
+#define TEMX_CSUM_REC(grp, dt, ndt) ((int64_t)(grp) * (ndt) + (dt))
 #endif
 
 constexpr int CLS_MB = 4;                     // member rows per class and batch

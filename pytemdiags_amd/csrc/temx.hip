@@ -149,6 +149,64 @@ static int upload(DevBuf& b, const void* src, size_t bytes) {
   return TEMX_OK;
 }
 
+// A buffer that a sweep streams into while it reads the fields.  On MI355X the write bandwidth of a large
+// allocation is bimodal with its physical placement -- a zero fill of 6.7 GB runs at 5.3-5.6 or at 6.3-6.5
+// TB/s, reads do not care -- and a sweep whose class sums go to a slow one loses ~5 % (tools/sweep_lab.hip
+// built with -DLAB_OFFSETS, profiles/r03_lab_csum_placement.log).  So: allocate up to TEMX_PLACE_TRIES
+// candidates (held together, so that each comes from other memory), time a zero fill of each, keep the
+// fastest.  The fill is also the initialisation the callers need.  Small buffers are not probed.
+__global__ void fill_zero_kernel(double2* __restrict__ p, int64_t n) {
+  const double2 z = make_double2(0.0, 0.0);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = z;
+}
+
+static int alloc_write_stream(DevBuf& b, size_t need) {
+  need = (need + 15) & ~(size_t)15;
+  if (b.bytes >= need) return TEMX_OK;          // (kept from an earlier configuration: already chosen)
+  int tries = 4;
+  if (const char* e = getenv("TEMX_PLACE_TRIES")) tries = std::max(1, std::min(8, atoi(e)));
+  if (need < ((size_t)1 << 30)) tries = 1;
+  b.release();
+  std::vector<DevBuf> cand;
+  std::vector<float> ms;
+  hipEvent_t ea = nullptr, eb = nullptr;
+  if (tries > 1 && (hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess)) tries = 1;
+  int best = -1;
+  float slowest = 0.f;
+  for (int t = 0; t < tries; ++t) {
+    size_t fr = 0, tot = 0;
+    if (t > 0 && (hipMemGetInfo(&fr, &tot) != hipSuccess || need > fr / 2)) break;
+    DevBuf c;
+    if (c.ensure(need) != TEMX_OK) {
+      if (t == 0) return TEMX_ENOMEM;
+      break;
+    }
+    float best_ms = 1e30f;
+    for (int rep = 0; rep < (tries > 1 ? 2 : 1); ++rep) {
+      if (ea) (void)hipEventRecord(ea, nullptr);
+      hipLaunchKernelGGL(fill_zero_kernel, dim3(2048), dim3(256), 0, nullptr, static_cast<double2*>(c.p), (int64_t)(need / 16));
+      if (ea) {
+        float m = 0.f;
+        (void)hipEventRecord(eb, nullptr);
+        if (hipEventSynchronize(eb) == hipSuccess && hipEventElapsedTime(&m, ea, eb) == hipSuccess) best_ms = std::min(best_ms, m);
+      }
+    }
+    cand.push_back(c);
+    ms.push_back(best_ms);
+    if (best < 0 || best_ms < ms[(size_t)best]) best = t;
+    slowest = std::max(slowest, best_ms);
+    // stop once both modes have been seen (or the first candidate is plainly a fast one)
+    if ((double)need / (best_ms * 1e-3) >= 6.1e12 || ms[(size_t)best] < 0.92f * slowest) break;
+  }
+  if (ea) (void)hipEventDestroy(ea);
+  if (eb) (void)hipEventDestroy(eb);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipGetLastError());
+  for (size_t i = 0; i < cand.size(); ++i)
+    if ((int)i == best) b = cand[i]; else cand[i].release();
+  return TEMX_OK;
+}
+
 // How to cut (d-tiles x chunk range) into wave-sized work so that `slots` workgroup slots
 // (CUs x resident workgroups) are evenly filled.  Smaller nsplit is preferred on near-ties
 // (fewer partial slabs to write and re-read).
@@ -1601,7 +1659,7 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
     const size_t need_cs = (size_t)pl->cgroups * ndt_ * 14 * 64 * 8, need_pb = (size_t)pl->cgroups * ndt_ * 3 * 128 * 8;
     size_t fr = 0, tot = 0;
     if (ndt_ >= 4 && !(e2 && e2[0] == '1') && hipMemGetInfo(&fr, &tot) == hipSuccess &&
-        (pl->csum.bytes >= need_cs || need_cs + need_pb < fr / 2) && pl->csum.ensure(need_cs) == TEMX_OK &&
+        (pl->csum.bytes >= need_cs || need_cs + need_pb < fr / 2) && alloc_write_stream(pl->csum, need_cs) == TEMX_OK &&
         pl->pbuf.ensure(need_pb) == TEMX_OK) {
       HIPCHK(hipMemset(pl->csum.p, 0, pl->csum.bytes));
       HIPCHK(hipMemset(pl->pbuf.p, 0, pl->pbuf.bytes));
@@ -1645,7 +1703,7 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
         const size_t need_cs = (size_t)pl->cgroups * ndt_ * 8 * 64 * 8;   // 4 {north, south} pairs per lane
         size_t fr = 0, tot = 0;
         bool have = pl->csum.bytes >= need_cs;
-        if (!have && hipMemGetInfo(&fr, &tot) == hipSuccess && need_cs < fr / 2 && pl->csum.ensure(need_cs) == TEMX_OK) {
+        if (!have && hipMemGetInfo(&fr, &tot) == hipSuccess && need_cs < fr / 2 && alloc_write_stream(pl->csum, need_cs) == TEMX_OK) {
           // lanes beyond a ragged last d-tile are never written but are read (and ignored) by the flux kernel
           HIPCHK(hipMemset(pl->csum.p, 0, pl->csum.bytes));
           have = true;

@@ -150,6 +150,13 @@ __global__ void maxdiff_kernel(const double* a, const double* b, int64_t n, doub
   }
 }
 
+__global__ void reader_kernel(const double2* in, int64_t nrec, double* sink) {
+  const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int lane = threadIdx.x & 63;
+  double a = 0.0;
+  for (int64_t r = wave; r < nrec; r += nw) { const double2 v = in[r * 64 + lane]; a += v.x + v.y; }
+  if (a == 1.2345e300) sink[0] = a;
+}
 // LAB_WRITER: a second kernel on its own stream writes `bytes` in 1 KB store instructions, `burst` stores in
 // flight per wave, while a sweep built without its class-sum stores (-DTEMX_CSTORE_NONE) runs
 __global__ void writer_kernel(double2* out, int64_t nrec /* 1 KB records */, int burst) {
@@ -301,7 +308,18 @@ int run(int64_t N, int64_t D, int reps, const char* only) {
           CHK(hipEventRecord(eb)); CHK(hipEventSynchronize(eb));
           float ms; CHK(hipEventElapsedTime(&ms, ea, eb)); sum2 += ms;
         }
-        printf("    class sums in %-40s %7.3f ms\n", what, sum2 / 3);
+        const int64_t nrec = (int64_t)csum_n * 8 / 1024;
+        float wms = 0.f, rms = 0.f, ms;
+        for (int r = 0; r < 2; ++r) {
+          CHK(hipEventRecord(ea));
+          hipLaunchKernelGGL(writer_kernel, dim3(2048), dim3(256), 0, 0, reinterpret_cast<double2*>(buf), nrec, 4);
+          CHK(hipEventRecord(eb)); CHK(hipEventSynchronize(eb)); CHK(hipEventElapsedTime(&ms, ea, eb)); wms = ms;
+          CHK(hipEventRecord(ea));
+          hipLaunchKernelGGL(reader_kernel, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const double2*>(buf), nrec, dm);
+          CHK(hipEventRecord(eb)); CHK(hipEventSynchronize(eb)); CHK(hipEventElapsedTime(&ms, ea, eb)); rms = ms;
+        }
+        printf("    class sums in %-40s %7.3f ms   (buffer alone: written in %.3f ms = %.2f TB/s, read in %.3f ms = %.2f TB/s)\n", what, sum2 / 3,
+               wms, csum_n * 8.0 / wms / 1e9, rms, csum_n * 8.0 / rms / 1e9);
       };
       tm("the buffer allocated before the fields", early);
       tm("csum_ref (after the fields, memset)", csum_ref);
