@@ -12,17 +12,18 @@ N = 1   : the workload BASELINE.json's target is quoted on, ne120 (777602 column
 N > 1   : one rank per GPU over RCCL, launched by `python -m torch.distributed.run --nproc-per-node N
           ... bench.py --gpus N`; invoked directly (`python bench.py --gpus N`) it starts that
           launcher itself as a child process, before anything touches the GPU, and returns its
-          exit code.  Default `--shard time`: every rank holds its own block of 30 snapshots of
-          the same grid (weak scaling, no data-path collective); the same job ncol-sharded (one
-          ne120x72x30 block in total, columns split in whole latitude classes, the zonal sums
-          all-reduced over RCCL: strong scaling) is timed afterwards and reported beside it as
-          "ncol_sharded".  `--shard ncol` makes that the metric.
+          exit code.  The metric is BASELINE.json configs[3]: ONE ne120x72x30 job, its columns sharded
+          over the ranks in whole latitude classes, the zonal sums all-reduced over RCCL/xGMI (strong
+          scaling: total work fixed).  Reported beside it under "other_workloads": configs[2],
+          ne30 x 72 x 730 snapshots time-sharded (91/92 per rank at N = 8, no collective; strong
+          scaling), and the weak-scaling run (every rank its own ne120x72x30 block, no collective).
+          A failure of any leg is written into the record and the process exits non-zero (4; a
+          stalled collective: 3).  `--shard time` makes the weak-scaling run the metric instead.
 Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
-import socket
 import subprocess
 import sys
 import threading
@@ -107,11 +108,9 @@ def cpu_baseline_config1_literal():
 def self_launch(argv, ngpus):
     """`python bench.py --gpus N` without a launcher: become the parent of torch.distributed.run.
     Nothing here has touched the GPU (no HIP call, no torch.cuda query)."""
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    # --standalone: the launcher's own c10d rendezvous picks a free port and keeps it (no bind/close/reuse race)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(ngpus), os.path.abspath(__file__)] + argv
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.run(cmd, env=env).returncode
@@ -123,7 +122,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="ne120x72x30")
-    ap.add_argument("--shard", choices=["time", "ncol"], default="time")
+    ap.add_argument("--shard", choices=["auto", "time", "ncol"], default="auto",
+                    help="auto: unsharded at N = 1, ncol at N > 1 (BASELINE configs[3], strong scaling); time: every "
+                         "rank its own block of snapshots (weak scaling)")
+    ap.add_argument("--time-workload", default="ne30x72x730",
+                    help="N > 1: the time-sharded job reported under other_workloads (BASELINE configs[2])")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-nt", type=int, default=2)
@@ -133,15 +136,14 @@ def main():
                     help="latitude-class sweeps in their two-pass form (fields read twice)")
     ap.add_argument("--no-classes", action="store_true",
                     help="do not use the latitude-class sweeps (mirror-paired sweeps on a symmetric grid)")
-    ap.add_argument("--no-ncol-extra", action="store_true",
-                    help="N > 1, time sharding: skip the extra strong-scaling run of the same job ncol-sharded "
-                         "over RCCL (reported as \"ncol_sharded\", not the metric)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N > 1: skip the legs reported beside the metric (time-sharded configs[2], weak scaling)")
     ap.add_argument("--also", default="ne30x72x1,ne30x72x91,ne240x128x1:f32,ne120x72x30:f64:generic",
                     help="comma list of the other BASELINE.json shapes, timed after the main one at N=1 "
                          "(shape[:f32|f64][:generic]; ne30x72x91 is one rank's block of the 730-snapshot config; "
                          ":generic forces the generic sweeps -- what a grid without repeated latitudes gets)")
-    ap.add_argument("--stall-timeout", type=float, default=240.0,
-                    help="N > 1: seconds the extra ncol-sharded run may take before the watchdog reports it stalled")
+    ap.add_argument("--stall-timeout", type=float, default=300.0,
+                    help="N > 1: seconds the whole run may take before the watchdog reports a stalled collective")
     args = ap.parse_args()
     if args.two_pass:
         os.environ["TEMX_TWO_PASS"] = "1"
@@ -178,7 +180,25 @@ def main():
     ncol = lat.size
 
     # ---- shard ----
+    if args.shard == "auto":
+        args.shard = "ncol" if world > 1 else "none"
     use_ncol = args.shard == "ncol"          # at world 1 the all-reduces are no-ops (path check)
+    errors = {}
+
+    # A collective that never completes blocks inside C code, where no Python signal handler runs: the
+    # watchdog is a daemon thread; it prints what there is with the error and ends the rank with exit code 3.
+    partial_rec = {"metric": "grid-points/sec through full TEM pipeline (ncol*nlev*nt)", "value": 0.0,
+                   "unit": "grid-points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup}
+    watchdog = None
+    if world > 1:
+        def _stalled():
+            partial_rec["errors"] = dict(errors, stall="no result after %.0f s" % args.stall_timeout)
+            if rank == 0:
+                print(json.dumps(partial_rec), flush=True)
+            os._exit(3)
+        watchdog = threading.Timer(args.stall_timeout, _stalled)
+        watchdog.daemon = True
+        watchdog.start()
     if use_ncol:
         # whole mirror pairs per rank: every rank's block of columns stays equatorially symmetric
         mine = sharding.symmetric_ncol_shards(lat, world)[rank]
@@ -270,6 +290,10 @@ def main():
         "hbm_roofline_bytes_per_point": (4 if plan.one_pass else 8) * (8 if args.dtype == "f64" else 4),
         "nonfinite": bool(nonfinite),
     }
+    if use_ncol:
+        rec["config"]["collectives"] = ("2 all-reduces per step over %s ([4][K][D] and [3][K][D] fp64 = %d bytes) + the "
+                                        "K x K Gram matrix once at plan build"
+                                        % ("RCCL/xGMI" if backend == "nccl" else backend, 7 * K_HARM * nlev * nt * 8))
     if neddy:
         ach = 7 * 2 * K_HARM * pts_rank / (eddy_ms * 1e-3) / 1e12
         if plan.one_pass and nproj:
@@ -384,62 +408,128 @@ def main():
                                             "ok": bool(err <= 1e-10 and not bad), "one_pass": bool(op_s)}
     plan.close()
 
-    if world > 1 and not use_ncol and not args.no_ncol_extra:
-        # BASELINE config 4: the same job (one ne120x72x30 block in total) with the columns sharded over
-        # the ranks and the zonal sums all-reduced over RCCL/xGMI -- strong scaling, reported beside
-        # the metric.  A watchdog prints the main record and leaves if a collective stalls.
-        # A collective that never completes blocks inside C code, where no Python signal handler runs:
-        # the watchdog is a daemon thread; it prints the record with the error and ends the rank with a
-        # non-zero exit code (the stall is a failure; its cause is to be found from the logs).
-        def _stalled():
-            rec["ncol_sharded"] = {"error": "stalled: no result after %.0f s" % args.stall_timeout}
-            if rank == 0:
-                print(json.dumps(rec), flush=True)
-            os._exit(3)
+    partial_rec.update(rec)
 
-        watchdog = threading.Timer(args.stall_timeout, _stalled)
-        watchdog.daemon = True
-        watchdog.start()
+    def timed(step_fn):
+        """W warm-up steps, then exactly K steps between barrier + synchronize; max over the ranks."""
+        for _ in range(max(args.warmup, 1)):
+            step_fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_fn()
+        barrier()
+        e = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        return float(e.item())
+
+    def leg(name, fn):
+        """An extra leg: its record under other_workloads; a failure is recorded and fails the run."""
         try:
-            del fields, out
-            torch.cuda.empty_cache()
-            mine = sharding.symmetric_ncol_shards(lat, world)[rank]
-            p3 = engine.Plan(lat[mine], lat_zm, K_HARM - 1, device=local_rank, defer_finalize=True,
-                             symmetry=not args.no_symmetry, classes=not args.no_classes)
-            runner3 = sharding.NcolShardedTEM(p3)           # all-reduce of the Gram matrix
-            p3.set_tem(nlev, nt, plev * 100)
-            f3 = engine.synth_fields(local_rank, lat[mine], lon[mine], plev, nt, t0=0, dtype=tdtype, seed=0)
-            for _ in range(max(args.warmup, 1)):
-                runner3.run(*f3)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                runner3.run(*f3)
-            barrier()
-            e3 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-            dist.all_reduce(e3, op=dist.ReduceOp.MAX)
-            e3 = float(e3.item())
-            bad3 = p3.status()
-            rec["ncol_sharded"] = {
-                "scaling": "strong", "value": ncol * nlev * nt * args.steps / e3, "unit": "grid-points/s",
-                "ms_per_step": e3 / args.steps * 1e3, "n_gpus": world, "ranks_in_process_group": dist.get_world_size(),
-                "workload": "ne%d (%d cols) x %d lev x %d snapshots per job, columns sharded in whole latitude classes"
-                            % (ne, ncol, nlev, nt),
-                "collectives": "2 RCCL all-reduces per step ([4][K][D] and [3][K][D] fp64 = %d bytes) + the "
-                               "K x K Gram matrix once at plan build" % (7 * K_HARM * nlev * nt * 8),
-                "sweeps": ("generic", "mirror-paired", "latitude-class")[p3.sweep_mode]
-                          + (", one pass" if p3.one_pass else ""), "nonfinite": bool(bad3)}
-            p3.close()
-        except Exception as e:  # noqa: BLE001 - the metric line must survive a failure of the extra
-            rec["ncol_sharded"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        watchdog.cancel()
+            if os.environ.get("TEMX_BENCH_FAIL") == name:      # tests: a forced failure of this leg
+                raise RuntimeError("forced failure of leg %r (TEMX_BENCH_FAIL)" % name)
+            rec.setdefault("other_workloads", {})[name] = fn()
+        except Exception as e:  # noqa: BLE001 - reported in the line, and through the exit code
+            errors[name] = "%s: %s" % (type(e).__name__, e)
+        torch.cuda.empty_cache()
 
+    if world > 1 and not args.no_extras:
+        del fields, out
+        torch.cuda.empty_cache()
+
+        def time_sharded():
+            # BASELINE configs[2]: one job of nt_all snapshots, each rank its own contiguous block (ragged
+            # blocks: 91/92 at N = 8), replicated plan, no collective on the data path; strong scaling
+            ne2, nlev2, nt_all = parse_workload(args.time_workload)
+            lat2, lon2 = synth.cubed_sphere_gll(ne2)
+            plev2 = synth.pressure_levels(nlev2)
+            ta, tb = sharding.shard_bounds(nt_all, world, rank)
+            p2 = engine.Plan(lat2, lat_zm, K_HARM - 1, device=local_rank, symmetry=not args.no_symmetry,
+                             classes=not args.no_classes)
+            p2.set_tem(nlev2, tb - ta, plev2 * 100)
+            f2 = engine.synth_fields(local_rank, lat2, lon2, plev2, tb - ta, t0=ta, dtype=tdtype, seed=0)
+            o2 = p2._alloc_results(False)
+            e2 = timed(lambda: p2.tem_run(*f2, out=o2))
+            bad2 = p2.status()
+            r = {"scaling": "strong", "shard": "time", "value": lat2.size * nlev2 * nt_all * args.steps / e2,
+                 "unit": "grid-points/s", "ms_per_step": e2 / args.steps * 1e3, "n_gpus": world,
+                 "workload": "ne%d (%d cols) x %d lev x %d snapshots per job, %d..%d per rank, no collective"
+                             % (ne2, lat2.size, nlev2, nt_all, nt_all // world, -(-nt_all // world)),
+                 "snapshots_this_rank": tb - ta,
+                 "sweeps": ("generic", "mirror-paired", "latitude-class")[p2.sweep_mode]
+                           + (", one pass" if p2.one_pass else ""), "nonfinite": bool(bad2)}
+            p2.close()
+            if bad2:
+                raise RuntimeError("non-finite values in the time-sharded run")
+            return r
+
+        def ncol_sharded():
+            # BASELINE configs[3] when the metric is the weak-scaling run (--shard time)
+            mine3 = sharding.symmetric_ncol_shards(lat, world)[rank]
+            p3 = engine.Plan(lat[mine3], lat_zm, K_HARM - 1, device=local_rank, defer_finalize=True,
+                             symmetry=not args.no_symmetry, classes=not args.no_classes)
+            r3 = sharding.NcolShardedTEM(p3)
+            p3.set_tem(nlev, nt, plev * 100)
+            f3 = engine.synth_fields(local_rank, lat[mine3], lon[mine3], plev, nt, t0=0, dtype=tdtype, seed=0)
+            e3 = timed(lambda: r3.run(*f3))
+            bad3 = p3.status()
+            r = {"scaling": "strong", "shard": "ncol", "value": ncol * nlev * nt * args.steps / e3,
+                 "unit": "grid-points/s", "ms_per_step": e3 / args.steps * 1e3, "n_gpus": world,
+                 "workload": "ne%d (%d cols) x %d lev x %d snapshots per job, columns sharded in whole latitude "
+                             "classes" % (ne, ncol, nlev, nt),
+                 "sweeps": ("generic", "mirror-paired", "latitude-class")[p3.sweep_mode]
+                           + (", one pass" if p3.one_pass else ""), "nonfinite": bool(bad3)}
+            p3.close()
+            if bad3:
+                raise RuntimeError("non-finite values in the ncol-sharded run")
+            return r
+
+        def weak():
+            # every rank its own block of nt snapshots of the whole grid: work grows with N, no collective
+            p4 = engine.Plan(lat, lat_zm, K_HARM - 1, device=local_rank, symmetry=not args.no_symmetry,
+                             classes=not args.no_classes)
+            p4.set_tem(nlev, nt, plev * 100)
+            f4 = engine.synth_fields(local_rank, lat, lon, plev, nt, t0=rank * nt, dtype=tdtype, seed=0)
+            o4 = p4._alloc_results(False)
+            e4 = timed(lambda: p4.tem_run(*f4, out=o4))
+            bad4 = p4.status()
+            r = {"scaling": "weak", "shard": "time", "value": ncol * nlev * nt * world * args.steps / e4,
+                 "unit": "grid-points/s", "ms_per_step": e4 / args.steps * 1e3, "n_gpus": world,
+                 "workload": "ne%d (%d cols) x %d lev x %d snapshots per GPU, no collective" % (ne, ncol, nlev, nt),
+                 "nonfinite": bool(bad4)}
+            p4.close()
+            if bad4:
+                raise RuntimeError("non-finite values in the weak-scaling run")
+            return r
+
+        leg("%s:time_sharded" % args.time_workload, time_sharded)
+        if use_ncol:
+            leg("%s:weak_scaling" % args.workload, weak)
+        else:
+            leg("%s:ncol_sharded" % args.workload, ncol_sharded)
+
+    if os.environ.get("TEMX_BENCH_FAIL") == "main":
+        errors["main"] = "RuntimeError: forced failure of the metric leg (TEMX_BENCH_FAIL)"
+    if rec.get("nonfinite"):
+        errors["main"] = "non-finite values reached the zonal sums of the metric run"
+    if watchdog is not None:
+        watchdog.cancel()
     if world > 1:
         rec["process_group"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size()}
+        # a leg may have failed on another rank only: every rank must leave with the same code
+        nerr = torch.tensor([float(len(errors))], dtype=torch.float64, device=dev)
+        dist.all_reduce(nerr, op=dist.ReduceOp.MAX)
+        if nerr.item() > 0 and not errors:
+            errors["other_rank"] = "a leg failed on another rank"
+    if errors:
+        rec["errors"] = errors
     if rank == 0:
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if errors:
+        sys.exit(4)
 
 
 if __name__ == "__main__":

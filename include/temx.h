@@ -110,7 +110,13 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
 int temx_plan_finalize(temx_plan* plan, const double* G_host /* [K][K] or NULL */);
 
 /* weights mode of the operator (sph_zonal_mean.py:180-181, 383-386): Y0inv = Y0^T diag(4 pi w).
- * Replaces the Gram solve by a per-column scale; call instead of temx_plan_finalize. */
+ * Replaces the Gram solve by a per-column scale; call instead of temx_plan_finalize.
+ * The operator API (temx_project / temx_zonal_mean) costs what it costs unweighted.  The TEM and tracer
+ * stages on a weighted plan run the UNFUSED second sweep (native means materialised, elementwise eddies,
+ * weighted projection -- the projection rows differ from the reconstruction rows, which the fused sweeps
+ * cannot express): workspace of 8 x ncol x nlev x nt doubles and about 8 x the HBM traffic of the fused
+ * path; TEMX_ENOMEM with the byte count when that does not fit -- use smaller blocks of snapshots.
+ * (TEMDiagnostics never builds a weighted averager, tem_diagnostics.py:241-247; this is C-ABI only.) */
 int temx_plan_set_weights(temx_plan* plan, const double* weights_host /* [ncol], sums to 1 */);
 
 void temx_plan_destroy(temx_plan* plan);

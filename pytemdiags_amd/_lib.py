@@ -11,6 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TEMX_LIB") or os.path.join(_HERE, "libtemx.so")   # TEMX_LIB: A/B builds
 
+ABI_VERSION = 300           # temx_version() of the library these bindings were written for (include/temx.h)
 F64, F32 = 0, 1
 DEFER_FINALIZE = 1
 NO_SYMMETRY = 2
@@ -95,9 +96,23 @@ def load():
     except ImportError:      # plain-C / ctypes-only consumers use the system runtime
         pass
     lib = C.CDLL(LIB_PATH)
+    ab_build = "TEMX_LIB" in os.environ      # A/B builds of another source tree (development only)
+    lib.temx_version.restype = _i
+    have = int(lib.temx_version())
+    if have != ABI_VERSION:
+        msg = "pytemdiags_amd: %s reports ABI version %d, these bindings expect %d" % (LIB_PATH, have, ABI_VERSION)
+        if not ab_build:
+            raise RuntimeError(msg + "; rebuild it (make -C pytemdiags_amd/csrc)")
+        import warnings
+        warnings.warn(msg + " (TEMX_LIB build: continuing)")
     for name, res, args in SIGNATURES:
-        if "TEMX_LIB" in os.environ and not hasattr(lib, name):
-            continue                     # A/B builds of an older source tree (development only)
+        if ab_build and not hasattr(lib, name):
+            # fail at the call, with the same message on every rank, instead of an AttributeError somewhere
+            # inside a collective sequence
+            def _missing(*_a, _n=name):
+                raise TemxError(-6, "symbol %s is missing in the TEMX_LIB build %s" % (_n, LIB_PATH))
+            setattr(lib, name, _missing)
+            continue
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args

@@ -127,6 +127,8 @@ struct temx_plan {
   Split sp_lflux;
   // op_valid: csum (and Pq) hold the class sums of the latest temx_tem_stage1 on this plan
   bool onepass = false, op_valid = false;
+  // c4_valid: C4 holds the coefficients of the fields of the latest temx_tem_stage1 (a stage-2 solve has run since)
+  bool c4_valid = false;
   DevBuf csum, ccnt;
   DevBuf Pq;                     // [3][K][D] projections of the co-moments of u v, u omega, v theta (sweep 1)
   // one-pass tracer: class sums of q ([groups][d-tiles][64] {north, south} pairs) and the projected
@@ -1214,7 +1216,7 @@ static FieldPtrs<4> four(const void* a, const void* b, const void* c, const void
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int temx_version(void) { return 200; }
+int temx_version(void) { return 300; }
 
 const char* temx_last_error(void) { return g_err.c_str(); }
 
@@ -1773,6 +1775,7 @@ int temx_tem_stage1(temx_plan* pl, const void* ua, const void* va, const void* t
   const Split& sp = pl->cls ? pl->sp_cproj4 : (sp4 ? pl->sp_sproj4 : pl->sp_proj4);
   const bool op = pl->cls && pl->onepass;
   pl->op_valid = false;
+  pl->c4_valid = false;          // C4 still describes the previous fields until a stage-2 solve has run
   pl->tq_valid = false;          // tracer class sums pair with the v, omega sums of one TEM run
   rc = op      ? launch_sweep_op<0>(pl, fp, dtype, pl->partial.d(), sp, st)
        : pl->cls ? launch_project_cls<4>(pl, fp, dtype, pl->D, pl->colscale.d(), 2, pl->partial.d(), sp, st)
@@ -1797,6 +1800,13 @@ int temx_tem_stage1(temx_plan* pl, const void* ua, const void* va, const void* t
 static int large_ws(temx_plan* pl) {
   const size_t nd = (size_t)pl->N * pl->D * 8;
   int rc;
+  // 8 arrays of ncol x nlev x nt doubles (107 GB at ne120 x 72 x 30): say so before the allocator does
+  size_t fr = 0, tot = 0;
+  const size_t have = pl->XB.bytes + pl->P3.bytes;
+  if (have < 8 * nd && hipMemGetInfo(&fr, &tot) == hipSuccess && 8 * nd - have > fr)
+    return fail(TEMX_ENOMEM, "the unfused second sweep (L > 63 without latitude classes, or a weighted plan) needs "
+                             "%zu bytes of workspace (8 x ncol x nlev x nt doubles), %zu are free; process the "
+                             "snapshots in smaller blocks (temx_plan_set_tem with a smaller nt)", 8 * nd - have, fr);
   if ((rc = pl->XB.ensure(5 * nd))) return rc;     // ub vb thetab wapb (+ qb for tracers), native
   return pl->P3.ensure(3 * nd);
 }
@@ -1841,6 +1851,7 @@ static int tem_stage2_large(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, co
   if ((rc = large_ws(pl))) return rc;
   const int64_t nd = pl->N * pl->D;
   if ((rc = launch_solve(pl, B4, 4, pl->D, pl->C4.d(), pl->zb.d(), st))) return rc;
+  pl->c4_valid = true;
   for (int f = 0; f < 4; ++f)
     if ((rc = launch_recon(pl, pl->D, pl->C4.d() + (int64_t)f * pl->K4 * pl->D, pl->XB.d() + f * nd, st))) return rc;
   EddyOut eo{};
@@ -1864,6 +1875,7 @@ int temx_tem_stage2(temx_plan* pl, const void* ua, const void* va, const void* t
   if (unfused_stage2(pl)) return tem_stage2_large(pl, four(ua, va, ta, wap), dtype, B4, B3, st);
   // C = G^-1 B4 and the four zonal means ub vb thetab wapb -> zb[0..3]
   if ((rc = launch_solve(pl, B4, 4, pl->D, pl->C4.d(), pl->zb.d(), st))) return rc;
+  pl->c4_valid = true;
   TimedLaunch tl{};
   time_begin(pl, 1, st, tl);
   rc = run_eddy<0>(pl, four(ua, va, ta, wap), dtype, pl->C4.d(), pl->partial.d(), nullptr, st);
@@ -1883,6 +1895,7 @@ int temx_tem_stage2_from_sums(temx_plan* pl, const double* B4, double* B3, void*
   HIPCHK(hipSetDevice(pl->device));
   hipStream_t st = S_(stream);
   if ((rc = launch_solve(pl, B4, 4, pl->D, pl->C4.d(), pl->zb.d(), st))) return rc;
+  pl->c4_valid = true;
   if (pl->large) {
     if ((rc = launch_flux_large(pl, pl->C4.d(), st))) return rc;
     pl->xb_valid = false;          // the native means are not materialised on this path
@@ -2063,6 +2076,8 @@ int temx_tracer_stage3(temx_plan* pl, const double* Bq2, double* tres, double* t
   return TEMX_OK;
 }
 
+// the one-pass tracer stages pair q's class sums with the v, omega class sums (csum: stage 1) and with the v,
+// omega coefficients (C4: stage 2) of the latest TEM run; both must describe the same fields
 static inline bool tracer_one_pass(const temx_plan* pl) { return pl->cls && pl->onepass && pl->op_valid; }
 
 int temx_tracer_stage1_sums(temx_plan* pl, const void* q, const void* va, const void* wap, int dtype,
@@ -2093,6 +2108,9 @@ int temx_tracer_stage2_from_sums(temx_plan* pl, const double* Bq, double* Bq2, v
   int rc = tem_ready(pl);
   if (rc) return rc;
   if (!Bq || !Bq2) return fail(TEMX_EINVAL, "null argument");
+  if (tracer_one_pass(pl) && !pl->c4_valid)
+    return fail(TEMX_ESTATE, "temx_tem_stage1 ran on new fields but no temx_tem_stage2 since: the v, omega "
+                             "coefficients belong to the previous fields");
   if (!tracer_one_pass(pl) || !pl->tq_valid)
     return fail(TEMX_ESTATE, "no tracer class sums: temx_tracer_stage1_sums must precede temx_tracer_stage2_from_sums");
   HIPCHK(hipSetDevice(pl->device));

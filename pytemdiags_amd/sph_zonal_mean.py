@@ -49,7 +49,10 @@ class sph_zonal_averager:
         self.L = L
         self.lat = _as_numpy(lat)                    # sph_zonal_mean.py:148-151
         self.lat_out = _as_numpy(lat_out)
-        self.weights = weights
+        # the caller's weights as float64 (sum to 1); the reference scales its attribute by 4 pi only AFTER the
+        # cache probe below (:177-181) -- the engine always takes the unscaled ones
+        self._w_raw = None if weights is None else _as_numpy(weights).astype(np.float64)
+        self.weights = self._w_raw
         self.grid_name = grid_name
         self.grid_out_name = grid_out_name
         self.save_dest = save_dest
@@ -78,8 +81,8 @@ class sph_zonal_averager:
         # the reference probes the map cache here (read_only=True, :177); there is no cache
         self.sph_compute_matrices(read_only=True, overwrite=overwrite)
         # scale grid weights to unit sphere surface area (:180-181); not in place
-        if self.weights is not None:
-            self.weights = _as_numpy(self.weights).astype(np.float64) * (4 * np.pi)
+        if self._w_raw is not None:
+            self.weights = self._w_raw * (4 * np.pi)
 
     # ---- matrices (attributes Y0, Y0inv, Y0p of the reference, fetched lazily from the device) ----
     def _matrix(self, which):
@@ -101,8 +104,8 @@ class sph_zonal_averager:
     def Y0inv(self):
         if self._plan is None:
             return None
-        if self.weights is not None:                 # Y0inv = Y0^T diag(w)  (:385)
-            return self.Y0.T * self.weights[None, :]
+        if self._w_raw is not None:                  # Y0inv = Y0^T diag(4 pi w)  (:385, weights scaled at :181)
+            return self.Y0.T * (self._w_raw * (4 * np.pi))[None, :]
         return self._matrix(_lib.MAT_Y0INV)
 
     # ---- map cache files (sph_zonal_mean.py:329-345, 400-417) ----
@@ -144,28 +147,34 @@ class sph_zonal_averager:
         if read_only and cached is None:
             return                                   # no cache on file (:343-345)
         from . import engine
-        if self.weights is not None and len(self.weights) != len(self.lat):
+        weighted = self._w_raw is not None
+        if weighted and len(self._w_raw) != len(self.lat):
             raise RuntimeError("number of weights must equal number of native grid latitudes!")   # :353-354
         if self._plan is not None:
             self._plan.close()
         self._cache = {}
-        self._plan = engine.Plan(self.lat, self.lat_out, self.L, device=self.device,
-                                 defer_finalize=self.weights is not None)
-        if self.weights is not None:
-            self._plan.set_weights(self.weights / (4 * np.pi))
+        self._plan = engine.Plan(self.lat, self.lat_out, self.L, device=self.device, defer_finalize=weighted)
+        if weighted:
+            self._plan.set_weights(self._w_raw)
         if cached is not None:
-            # the engine applies its own factorisation of the same operator; a cache is accepted only if
-            # it describes this grid and L
-            ok = (np.max(np.abs(cached[0] - self.Y0)) <= 1e-9 and np.max(np.abs(cached[2] - self.Y0p)) <= 1e-9
-                  and np.max(np.abs(cached[1] @ cached[0] - np.eye(self.L + 1))) <= 1e-6)
+            # the engine applies its own factorisation of the same operator (built above for THIS grid, L and
+            # weights); a cache is accepted only if it describes them too.  Quadrature weights do not make
+            # Y0inv Y0 the identity, so in weights mode the cached Y0inv is compared with Y0^T diag(4 pi w).
+            ok = np.max(np.abs(cached[0] - self.Y0)) <= 1e-9 and np.max(np.abs(cached[2] - self.Y0p)) <= 1e-9
+            if ok and weighted:
+                ref = self.Y0inv
+                ok = np.max(np.abs(cached[1] - ref)) <= 1e-9 * max(1.0, float(np.max(np.abs(ref))))
+            elif ok:
+                ok = np.max(np.abs(cached[1] @ cached[0] - np.eye(self.L + 1))) <= 1e-6
             if ok:
                 self._cache[_lib.MAT_Y0], self._cache[_lib.MAT_Y0P] = cached[0], cached[2]
-                if self.weights is None:
+                if not weighted:
                     self._cache[_lib.MAT_Y0INV] = cached[1]
                 self.map_cache_used = True
                 return
             import warnings
-            warnings.warn("map cache {} does not match this grid / L; recomputed".format(self.Y0_file_out))
+            warnings.warn("map cache {} does not match this grid / L / weights; ignored (the operator was "
+                          "built from the arguments)".format(self.Y0_file_out))
         self.map_cache_used = False
         if self._cache_on and not no_write and not read_only:
             self._write_map_cache()                  # :400-417

@@ -108,3 +108,38 @@ def test_two_ranks_on_one_gpu(mode):
     for i in range(ref.shape[0]):
         err = np.max(np.abs(got[i] - ref[i])) / np.max(np.abs(ref[i]))
         assert err <= 1e-11, (mode, i, err)
+
+
+def test_bench_line_at_two_ranks_and_failure_exit_code():
+    """`bench.py --gpus 2` reports BASELINE configs[3] (one job, ncol-sharded, strong scaling)
+    as the metric and configs[2] (time-sharded) beside it; a failing leg ends the run non-zero.  Rehearsed
+    with two ranks on this one GPU over gloo (TEMX_BENCH_BACKEND), small shapes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["TEMX_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "ne30x72x8", "--time-workload", "ne30x72x9", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["config"]["shard"] == "ncol"
+    assert rec["process_group"]["ranks"] == 2 and rec["value"] > 0 and "errors" not in rec
+    ow = rec["other_workloads"]
+    ts = ow["ne30x72x9:time_sharded"]
+    assert ts["scaling"] == "strong" and ts["shard"] == "time" and ts["snapshots_this_rank"] == 5 and ts["value"] > 0
+    assert ow["ne30x72x8:weak_scaling"]["scaling"] == "weak"
+    # a forced failure of the time-sharded leg: the line still comes out, with the error, and the exit code is 4
+    env["TEMX_BENCH_FAIL"] = "ne30x72x9:time_sharded"
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0, (p.stdout + p.stderr)[-3000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert "ne30x72x9:time_sharded" in rec["errors"]
+    # and of the metric leg itself
+    env["TEMX_BENCH_FAIL"] = "main"
+    p = subprocess.run(cmd + ["--no-extras"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0

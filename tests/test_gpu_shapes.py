@@ -597,5 +597,21 @@ def test_one_pass_tracer_reads_the_fields_once(force_one_pass, monkeypatch):
     plan.tem_stage1(*d)
     with pytest.raises(_lib.TemxError):
         plan.tracer_stage2_from_sums(Bq)
+    # TEM stage 1 on NEW fields, tracer stage 1, and no TEM stage 2 in between -- the v, omega
+    # coefficients (C4) still belong to the previous fields, so the tracer's stage 2 must refuse ...
+    f2 = synth.analytic_fields(lat, lon, plev, nt, seed=22)
+    d2 = [torch.as_tensor(x, device="cuda:0") for x in f2]
+    B4 = plan.tem_stage1(*d2)
+    Bq = plan.tracer_stage1_sums(dq[0], d2[1], d2[3])
+    with pytest.raises(_lib.TemxError) as ei:
+        plan.tracer_stage2_from_sums(Bq)
+    assert ei.value.code == -5
+    # ... and accept once the stage-2 solve of these fields has run; the answer is the one for (q, f2)
+    plan.tem_stage2_from_sums(B4)
+    t3, _ = plan.tracer_stage3(plan.tracer_stage2_from_sums(Bq))
+    ref2 = orc.TEMOracle(*f2, lat, plev, mode="factorised", q=[qs[0]])
+    for k, n in enumerate(_lib.TRACER_RESULT_NAMES):
+        e = fieldnorm_err(t3[k].cpu().numpy(), getattr(ref2, n)(0))
+        assert e <= 1e-10, (n, e)
     assert not plan.status()
     plan.close()
