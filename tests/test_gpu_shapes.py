@@ -607,7 +607,7 @@ def test_one_pass_tracer_reads_the_fields_once(force_one_pass, monkeypatch):
         plan.tracer_stage2_from_sums(Bq)
     assert ei.value.code == -5
     # ... and accept once the stage-2 solve of these fields has run; the answer is the one for (q, f2)
-    plan.tem_stage2_from_sums(B4)
+    plan.tem_stage3(plan.tem_stage2_from_sums(B4))      # (stage 3 leaves psi, vtem, omegatem for the tracer epilogue)
     t3, _ = plan.tracer_stage3(plan.tracer_stage2_from_sums(Bq))
     ref2 = orc.TEMOracle(*f2, lat, plev, mode="factorised", q=[qs[0]])
     for k, n in enumerate(_lib.TRACER_RESULT_NAMES):
