@@ -138,10 +138,11 @@ def main():
                     help="do not use the latitude-class sweeps (mirror-paired sweeps on a symmetric grid)")
     ap.add_argument("--no-extras", action="store_true",
                     help="N > 1: skip the legs reported beside the metric (time-sharded configs[2], weak scaling)")
-    ap.add_argument("--also", default="ne30x72x1,ne30x72x91,ne240x128x1:f32,ne120x72x30:f64:generic",
+    ap.add_argument("--also", default="ne30x72x1,ne30x72x91,ne240x128x1:f32,ne120x72x30:f64:generic,ne120x72x30:f64:shard1of8",
                     help="comma list of the other BASELINE.json shapes, timed after the main one at N=1 "
-                         "(shape[:f32|f64][:generic]; ne30x72x91 is one rank's block of the 730-snapshot config; "
-                         ":generic forces the generic sweeps -- what a grid without repeated latitudes gets)")
+                         "(shape[:f32|f64][:generic|:shardRofW]; ne30x72x91 is one rank's block of the 730-snapshot config; "
+                         ":generic forces the generic sweeps -- what a grid without repeated latitudes gets; :shardRofW is "
+                         "rank R's block of columns of the job ncol-sharded over W ranks, its stages without the all-reduces)")
     ap.add_argument("--stall-timeout", type=float, default=300.0,
                     help="N > 1: seconds the whole run may take before the watchdog reports a stalled collective")
     args = ap.parse_args()
@@ -356,14 +357,28 @@ def main():
             parts = wl.split(":")                             # "ne240x128x1:f32[:generic]" -> shape, input dtype, sweeps
             name, dt_s = parts[0], (parts[1] if len(parts) > 1 else "")
             generic = "generic" in parts[2:]
+            shard = [x for x in parts[2:] if x.startswith("shard")]
             dt2_t = {"": tdtype, "f64": torch.float64, "f32": torch.float32}[dt_s]
             ne2, nlev2, nt2 = parse_workload(name)
             try:
                 lat2, lon2 = synth.cubed_sphere_gll(ne2)
                 plev2 = synth.pressure_levels(nlev2)
-                p2 = engine.Plan(lat2, lat_zm, K_HARM - 1, device=local_rank, symmetry=not generic)
+                if shard:
+                    # one rank's block of the ncol-sharded job (whole latitude classes), finalised with the Gram
+                    # matrix of the whole grid as the all-reduce would leave it; tem_run = the rank's three stages
+                    from pytemdiags_amd import _lib
+                    r_s, w_s = (int(x) for x in shard[0][5:].split("of"))
+                    pg = engine.Plan(lat2, lat_zm, K_HARM - 1, device=local_rank)
+                    G2 = pg.matrix(_lib.MAT_GRAM).cpu().numpy()
+                    pg.close()
+                    mine2 = sharding.symmetric_ncol_shards(lat2, w_s)[r_s - 1]
+                    lat2, lon2 = lat2[mine2], lon2[mine2]
+                    p2 = engine.Plan(lat2, lat_zm, K_HARM - 1, device=local_rank, defer_finalize=True)
+                    p2.finalize(G2)
+                else:
+                    p2 = engine.Plan(lat2, lat_zm, K_HARM - 1, device=local_rank, symmetry=not generic)
                 p2.set_tem(nlev2, nt2, plev2 * 100)
-                same = name == args.workload and dt2_t == tdtype       # the headline's own fields: reuse them
+                same = name == args.workload and dt2_t == tdtype and not shard      # the headline's own fields: reuse them
                 f2 = fields if same else engine.synth_fields(local_rank, lat2, lon2, plev2, nt2, dtype=dt2_t, seed=0)
                 o2 = p2._alloc_results(False)
                 for _ in range(3):
@@ -379,7 +394,7 @@ def main():
                 dt2 = (time.perf_counter() - t0) / reps
                 pts2 = lat2.size * nlev2 * nt2
                 rec["other_workloads"][wl] = {
-                    "ms_per_step": dt2 * 1e3, "grid_points_per_s": pts2 / dt2, "reps": reps,
+                    "ms_per_step": dt2 * 1e3, "grid_points_per_s": pts2 / dt2, "reps": reps, "ncol": int(lat2.size),
                     "plan_symmetry": not generic,
                     "sweeps": ("generic", "mirror-paired", "latitude-class")[p2.sweep_mode]
                               + (", one pass" if p2.one_pass else ""),

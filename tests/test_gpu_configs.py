@@ -110,5 +110,65 @@ def test_config3_full_size_ne120x72x30_properties(monkeypatch):
     torch.cuda.empty_cache()
 
 
+def test_config3_full_size_eight_ncol_shards_equal_the_unsharded_run():
+    """BASELINE configs[3] as it is partitioned at 8 GPUs: the ne120 grid cut by
+    symmetric_ncol_shards(lat, 8), the staged C ABI run shard by shard on this one GPU with the three
+    all-reduces written out as explicit sums (Gram matrix, [4][K][D], [3][K][D]) -- sph_zonal_mean.py:251
+    is linear in the rows -- against the unsharded run of the same 53.7 GB, to 1e-11.  One shard's rows
+    are gathered at a time; the eight plans stay alive because stage 2 of the one-pass class path works
+    from the class sums its own stage 1 stored."""
+    from pytemdiags_amd import _lib, engine, sharding, synth
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test needs a GPU")
+    W = 8
+    lat, lon = synth.cubed_sphere_gll(120)
+    plev = synth.pressure_levels(72)
+    nt = 30
+    f = engine.synth_fields(0, lat, lon, plev, nt, dtype=torch.float64, seed=0)
+    full = engine.Plan(lat, _zm_lat(), 50)
+    full.set_tem(72, nt, plev * 100)
+    ref, _ = full.tem_run(*f)
+    ref = ref.clone()
+    assert not full.status()
+    full.close()
+    parts = sharding.symmetric_ncol_shards(lat, W)
+    assert sum(p.size for p in parts) == lat.size and np.array_equal(np.sort(np.concatenate(parts)), np.arange(lat.size))
+    a = np.abs(lat)
+    for r in range(W - 1):                       # whole latitude classes per rank
+        assert a[parts[r]].max() < a[parts[r + 1]].min()
+    plans = [engine.Plan(lat[p], _zm_lat(), 50, defer_finalize=True) for p in parts]
+    G = sum(pl.matrix(_lib.MAT_GRAM) for pl in plans).cpu().numpy()              # all-reduce (i)
+    B4 = None
+    for pl, p in zip(plans, parts):
+        pl.finalize(G)
+        pl.set_tem(72, nt, plev * 100)
+        idx = torch.as_tensor(p, device="cuda:0")
+        loc = [x[idx] for x in f]
+        b = pl.tem_stage1(*loc)                                                     # all-reduce (ii)
+        B4 = b if B4 is None else B4 + b
+        del loc
+    B3 = None
+    for pl, p in zip(plans, parts):
+        if pl.one_pass:
+            b = pl.tem_stage2_from_sums(B4)
+        else:
+            idx = torch.as_tensor(p, device="cuda:0")
+            b = pl.tem_stage2(*[x[idx] for x in f], B4)
+        B3 = b if B3 is None else B3 + b                                            # all-reduce (iii)
+    import os
+    if not any(os.environ.get(k) == "1" for k in ("TEMX_NO_SYM", "TEMX_NO_CLS", "TEMX_TWO_PASS")):
+        assert all(pl.sweep_mode == 2 and pl.one_pass for pl in plans)              # what each of the 8 ranks runs
+    for pl in (plans[0], plans[W - 1]):          # every rank evaluates the same epilogue
+        res, _ = pl.tem_stage3(B3)
+        for i, n in enumerate(_lib.RESULT_NAMES):
+            den = float(ref[i].abs().max())
+            assert float((res[i] - ref[i]).abs().max()) <= 1e-11 * den, n
+    assert not any(pl.status() for pl in plans)
+    for pl in plans:
+        pl.close()
+    del f
+    torch.cuda.empty_cache()
+
+
 def test_config4_ne240x128x1_f32_vs_oracle():
     _vs_oracle(240, 128, 1, torch.float32, 2e-5)
