@@ -56,7 +56,9 @@ enum {
   TEMX_MAT_Y0P = 1,   /* [M][K]   sph_zonal_mean.py:367-370 */
   TEMX_MAT_GRAM = 2,  /* [K][K]   Y0^T Y0 (this rank's rows only until finalised with a global G) */
   TEMX_MAT_GINV = 3,  /* [K][K]   inverse Gram; Y0inv = GINV . Y0^T */
-  TEMX_MAT_Y0INV = 4  /* [K][N]   pinv(Y0) as the reference stores it, sph_zonal_mean.py:389 */
+  TEMX_MAT_Y0INV = 4, /* [K][N]   pinv(Y0) as the reference stores it, sph_zonal_mean.py:389 */
+  TEMX_MAT_GRAM2 = 5  /* [K][K]   Q^T Q over this rank's rows, Q = Y0 R^-1 the basis the finalised plan projects
+                                  on (see temx_plan_finalize); the identity if the plan keeps the Y0 basis */
 };
 
 /* order of the ten GM16 Table-A1 results in the results buffer (tem_diagnostics.py:1018-1022) */
@@ -104,10 +106,28 @@ int temx_device_count(void);
 int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
                      const double* lat_deg_host, const double* lat_out_deg_host, int flags);
 
-/* ncol-sharded use: each rank creates its plan with TEMX_DEFER_FINALIZE over its own
- * columns, copies its local Gram out (temx_get_matrix(TEMX_MAT_GRAM)), all-reduces it, and
- * hands the global G back here.  G_host == NULL finalises with the local Gram. */
+/* Replaces lstsq(Y0, I_N) (sph_zonal_mean.py:389).  The Gram matrix G is factorised on the host (Cholesky,
+ * long double) and the plan is RE-ORTHOGONALISED (Cholesky-QR2): all basis blocks of the sweeps are rebuilt for
+ * Q = Y0 R^-1 (a row of Q still depends on latitude only), the sweeps project on Q, the K x K solve becomes
+ * (Q^T Q)^-1 ~ I and Y0p R^-1 takes the coefficients to the output latitudes.  Errors are of order
+ * cond(Y0) eps instead of the cond(Y0)^4 eps of an explicit inverse of the normal equations.  Consequences:
+ *   - the raw sums of this API (temx_project, B4, B3, Bq, Bq2) are Q^T A, not Y0^T A -- still linear in the
+ *     rows, so ncol-sharded callers all-reduce them exactly as before; every rank must finalise with the
+ *     SAME G (the all-reduced one);
+ *   - the attributes are unchanged: TEMX_MAT_Y0, TEMX_MAT_Y0P, TEMX_MAT_GINV = G^-1, TEMX_MAT_Y0INV = G^-1 Y0^T.
+ * Rank-deficient G (fewer distinct latitudes than harmonics): pseudo-inverse of G in the Y0 basis, as before.
+ * TEMX_NO_QR=1 in the environment keeps the Y0 basis and the explicit G^-1.
+ * ncol-sharded use: each rank creates its plan with TEMX_DEFER_FINALIZE over its own columns, copies its
+ * local Gram out (temx_get_matrix(TEMX_MAT_GRAM)), all-reduces it, and hands the global G back here.
+ * G_host == NULL finalises with the local Gram (and runs temx_plan_refine(plan, NULL) itself). */
 int temx_plan_finalize(temx_plan* plan, const double* G_host /* [K][K] or NULL */);
+
+/* Second pass of the re-orthogonalisation: (Q^T Q)^-1 from G2, the Gram matrix of Q.  G2_host == NULL:
+ * computed from this plan's rows (single-process use; temx_plan_finalize(plan, NULL) does it).  ncol-sharded
+ * use: all-reduce temx_get_matrix(TEMX_MAT_GRAM2) and hand it over; without this call a sharded plan uses
+ * the identity, which leaves errors of order cond(G) eps (fine for cond(G) up to ~1e5).  A no-op for plans
+ * that keep the Y0 basis. */
+int temx_plan_refine(temx_plan* plan, const double* G2_host /* [K][K] or NULL */);
 
 /* weights mode of the operator (sph_zonal_mean.py:180-181, 383-386): Y0inv = Y0^T diag(4 pi w).
  * Replaces the Gram solve by a per-column scale; call instead of temx_plan_finalize.
@@ -140,7 +160,8 @@ int temx_get_matrix(temx_plan* plan, int which, double* dst, void* stream);
 
 /* ---- operator API: replaces _sph_zonal_mean_generic (sph_zonal_mean.py:187-283) ------------ */
 
-/* B[K][D] = Y0^T A  (this rank's columns; raw sums, before G^-1).  A is [ncol][D]. */
+/* B[K][D] = Q^T A  (this rank's columns; raw sums in the plan's projection basis, Q = Y0 R^-1 after
+ * temx_plan_finalize, Y0 itself with TEMX_NO_QR=1, weights or a rank-deficient grid).  A is [ncol][D]. */
 int temx_project(temx_plan* plan, const void* A, int dtype, int64_t D, double* B, void* stream);
 
 /* out = (Y . Y0inv) . A   (sph_zonal_mean.py:251);  native == 0: Y = Y0p, out is [M][D]

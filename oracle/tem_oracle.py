@@ -18,9 +18,12 @@ Two association modes of the zonal-mean operator are provided:
 * ``mode='literal'``    -- exactly the reference's operation order: dense
   ``Y0inv = lstsq(Y0, I_N)[0]`` (sph_zonal_mean.py:389) and ``(Y @ Y0inv) @ A``
   (sph_zonal_mean.py:251).  O(N^2) memory: small grids only.
-* ``mode='factorised'`` -- the same linear operator written ``Y @ (G^-1 (Y0^T A))`` with
-  ``G = Y0^T Y0``.  O(N K) memory; this is the association the HIP engine uses and the
-  yard-stick at BASELINE.json's full sizes.
+* ``mode='factorised'`` -- the same linear operator without the N x N matrix: ``Y @ (R^-1 (Q^T A))``
+  with the thin QR factorisation ``Y0 = Q R`` (Householder; for a full-rank Y0 this IS
+  ``lstsq(Y0, I_N) @ A``, with errors of order cond(Y0) eps like the reference's SVD -- round 1 and 2
+  used ``inv(Y0^T Y0)``, whose cond(Y0)^4 eps error was the larger side of the comparison on
+  ill-conditioned random grids, profiles/r02_fuzz_seed_887.log).  O(N K) memory; the yard-stick at
+  BASELINE.json's full sizes.  A rank-deficient Y0 falls back to ``lstsq(Y0, A)``.
 """
 from __future__ import annotations
 
@@ -115,7 +118,10 @@ class ZonalAverager:
             self.Y0inv = scipy.linalg.lstsq(self.Y0, np.identity(self.N))[0]
         else:
             G = self.Y0.T @ self.Y0
-            self.Ginv = np.linalg.inv(G)
+            self.Ginv = np.linalg.inv(G)          # (attribute / sanity numbers only)
+            self._Q, self._R = np.linalg.qr(self.Y0)
+            d = np.abs(np.diagonal(self._R))
+            self._full_rank = bool(d.min() > 1e-12 * d.max())
 
     # sph_zonal_mean.py:393-394  (sanity numbers the reference prints)
     def sanity(self):
@@ -130,7 +136,9 @@ class ZonalAverager:
         """C = Y0inv @ AA  ([K, D])."""
         if self.Y0inv is not None:
             return self.Y0inv @ AA
-        return self.Ginv @ (self.Y0.T @ AA)
+        if not self._full_rank:                   # minimum-norm solution, as the reference's lstsq gives
+            return scipy.linalg.lstsq(self.Y0, AA)[0]
+        return scipy.linalg.solve_triangular(self._R, self._Q.T @ AA)
 
     def _generic(self, A, Y):
         """sph_zonal_mean.py:187-283."""
@@ -147,7 +155,7 @@ class ZonalAverager:
         if self.mode == "literal" or self.weights is not None:
             Abar = np.matmul(np.matmul(Y, self.Y0inv), AA)      # :251
         else:
-            Abar = Y @ (self.Ginv @ (self.Y0.T @ AA))
+            Abar = Y @ self.coefficients(AA)
         Abar = Abar.reshape((Y.shape[0],) + tuple(shape[1:]))   # :255
         return Abar.astype(prec)                  # :282
 

@@ -16,7 +16,7 @@ F64, F32 = 0, 1
 DEFER_FINALIZE = 1
 NO_SYMMETRY = 2
 NO_CLASSES = 4
-MAT_Y0, MAT_Y0P, MAT_GRAM, MAT_GINV, MAT_Y0INV = 0, 1, 2, 3, 4
+MAT_Y0, MAT_Y0P, MAT_GRAM, MAT_GINV, MAT_Y0INV, MAT_GRAM2 = 0, 1, 2, 3, 4, 5
 
 RESULT_NAMES = ("vtem", "omegatem", "wtem", "psitem", "epfy", "epfz", "epdiv",
                 "utendepfd", "utendvtem", "utendwtem")
@@ -39,6 +39,7 @@ SIGNATURES = [
     ("temx_device_count", _i, []),
     ("temx_plan_create", _i, [C.POINTER(_vp), _i, _i64, _i, _i, _dp, _dp, _i]),
     ("temx_plan_finalize", _i, [_vp, _dp]),
+    ("temx_plan_refine", _i, [_vp, _dp]),
     ("temx_plan_set_weights", _i, [_vp, _dp]),
     ("temx_plan_destroy", None, [_vp]),
     ("temx_plan_is_paired", _i, [_vp]),

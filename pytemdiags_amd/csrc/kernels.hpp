@@ -45,18 +45,16 @@ struct EddyOut {
 // Rows >= N and harmonics >= K are zero, so tails need no masking in the sweeps.
 // rowscale (weights mode, sph_zonal_mean.py:385) scales the blocked copy only.
 // ------------------------------------------------------------------------------------------------
-__global__ void basis_kernel(const double* __restrict__ x, int64_t N, int64_t nrow_pad, int K, int TB /* blocks stored per group */,
-                             const double* __restrict__ norm, const double* __restrict__ rowscale,
-                             double* __restrict__ Y0, double* __restrict__ yblk) {
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= nrow_pad) return;
-  const bool valid = i < N;
-  const double xv = valid ? x[i] : 0.0;
-  const double rs = (valid && rowscale) ? rowscale[i] : 1.0;
-  const int64_t group = i >> 2;
-  const int k = (int)(i & 3);
+// One row of the projection basis at x = cos(colat):  q[l] = Y_l^0(x) for l < K, or -- with T, the
+// inverse of the Cholesky factor of the Gram matrix (upper triangular, row-major K x K) --
+//     q[j] = sum_{l <= j} Y_l^0(x) T[l][j],
+// the row of Q = Y0 R^-1 (temx_plan_finalize: the sweeps then project on an orthonormal basis and the
+// K x K solve is the identity up to rounding).  In place from the highest column down: q[j] needs only l <= j.
+template <int KMAX>
+__device__ __forceinline__ void basis_row(double xv, int K, const double* __restrict__ norm,
+                                          const double* __restrict__ T, double* q) {
   double pm1 = 1.0, pc = xv;
-  for (int l = 0; l < 4 * TB; ++l) {
+  for (int l = 0; l < K; ++l) {
     double P;
     if (l == 0) {
       P = 1.0;
@@ -68,7 +66,32 @@ __global__ void basis_kernel(const double* __restrict__ x, int64_t N, int64_t nr
       pc = pn;
       P = pn;
     }
-    const double val = (valid && l < K) ? norm[l] * P : 0.0;
+    q[l] = norm[l] * P;
+  }
+  if (T != nullptr) {
+    for (int j = K - 1; j >= 0; --j) {
+      double a = 0.0;
+      for (int l = 0; l <= j; ++l) a += q[l] * T[(int64_t)l * K + j];
+      q[j] = a;
+    }
+  }
+}
+
+template <int KMAX>
+__global__ void basis_kernel(const double* __restrict__ x, int64_t N, int64_t nrow_pad, int K, int TB /* blocks stored per group */,
+                             const double* __restrict__ norm, const double* __restrict__ rowscale,
+                             const double* __restrict__ T, double* __restrict__ Y0, double* __restrict__ yblk) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= nrow_pad) return;
+  const bool valid = i < N;
+  const double xv = valid ? x[i] : 0.0;
+  const double rs = (valid && rowscale) ? rowscale[i] : 1.0;
+  const int64_t group = i >> 2;
+  const int k = (int)(i & 3);
+  double q[KMAX];
+  basis_row<KMAX>(xv, K, norm, T, q);
+  for (int l = 0; l < 4 * TB; ++l) {
+    const double val = (valid && l < K) ? q[l] : 0.0;
     if (Y0 && valid && l < K) Y0[i * K + l] = val;
     if (yblk) yblk[((group * TB + (l >> 2)) * 16) + k * 4 + (l & 3)] = val * rs;
   }

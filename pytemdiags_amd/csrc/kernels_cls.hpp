@@ -96,8 +96,10 @@ constexpr int CLS_ROWMASK = 0x07FFFFFF;
 constexpr int CLS_HASPAD_BIT = 1 << 27;       // the batch has at least one padding entry (set in all its entries)
 constexpr int CLS_SOUTH = 1, CLS_FIRST = 2, CLS_LAST = 4;   // flags, stored at bit 28
 
+template <int KMAX>
 __global__ void cls_basis_kernel(const double* __restrict__ xc, int64_t ncls, int64_t ncls_pad, int K, int TBS,
-                                 const double* __restrict__ norm, double* __restrict__ ycls) {
+                                 const double* __restrict__ norm, const double* __restrict__ T,
+                                 double* __restrict__ ycls) {
   int64_t ci = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (ci >= ncls_pad) return;
   const bool valid = ci < ncls;
@@ -105,20 +107,10 @@ __global__ void cls_basis_kernel(const double* __restrict__ xc, int64_t ncls, in
   const int64_t grp = ci >> 2;
   const int k = (int)(ci & 3);
   double* blk = ycls + grp * (2 * TBS * 16);
-  double pm1 = 1.0, pc = xv;
+  double q[KMAX];
+  basis_row<KMAX>(xv, K, norm, T, q);          // (T keeps the parity of a column: temx_plan_finalize)
   for (int l = 0; l < 8 * TBS; ++l) {
-    double P;
-    if (l == 0) {
-      P = 1.0;
-    } else if (l == 1) {
-      P = xv;
-    } else {
-      double pn = ((2 * l - 1) * xv * pc - (l - 1) * pm1) / l;
-      pm1 = pc;
-      pc = pn;
-      P = pn;
-    }
-    const double val = (valid && l < K) ? norm[l] * P : 0.0;
+    const double val = (valid && l < K) ? q[l] : 0.0;
     const int h = l >> 1;
     const int t = (l & 1) * TBS + (h >> 2);
     blk[t * 16 + k * 4 + (h & 3)] = val;
@@ -739,29 +731,20 @@ flux_cls_kernel(int64_t D, int K, int K4, const double* __restrict__ ycls, const
 //   flux_large_kernel        xbar at the class latitudes from all slices, algebraic eddy-product sums
 //                            -> pbuf[group][dt][3][64][2]
 // ------------------------------------------------------------------------------------------------
+template <int KMAX>
 __global__ void cls_basis_slice_kernel(const double* __restrict__ xc, int64_t ncls, int64_t ncls_pad, int K,
-                                       int l0, const double* __restrict__ norm, double* __restrict__ ycls) {
+                                       int l0, const double* __restrict__ norm, const double* __restrict__ T,
+                                       double* __restrict__ ycls) {
   int64_t ci = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (ci >= ncls_pad) return;
   const bool valid = ci < ncls;
   const double xv = valid ? xc[ci] : 0.0;
   double* blk = ycls + (ci >> 2) * (16 * 16);
   const int k = (int)(ci & 3);
-  double pm1 = 1.0, pc = xv;
-  for (int l = 0; l < l0 + 64; ++l) {
-    double P;
-    if (l == 0) {
-      P = 1.0;
-    } else if (l == 1) {
-      P = xv;
-    } else {
-      double pn = ((2 * l - 1) * xv * pc - (l - 1) * pm1) / l;
-      pm1 = pc;
-      pc = pn;
-      P = pn;
-    }
-    if (l < l0) continue;
-    const double val = (valid && l < K) ? norm[l] * P : 0.0;
+  double q[KMAX];
+  basis_row<KMAX>(xv, K, norm, T, q);
+  for (int l = l0; l < l0 + 64; ++l) {
+    const double val = (valid && l < K) ? q[l] : 0.0;
     const int h = (l - l0) >> 1;
     const int t = ((l - l0) & 1) * 8 + (h >> 2);
     blk[t * 16 + k * 4 + (h & 3)] = val;

@@ -24,9 +24,10 @@ namespace temx {
 
 constexpr int SYM_PROJ_CH = 3;   // pair-groups per chunk of the paired project sweep
 
+template <int KMAX>
 __global__ void sym_basis_kernel(const double* __restrict__ x, const int* __restrict__ rowN, int64_t npair,
                                  int64_t npair_pad, int K, int TBS, const double* __restrict__ norm,
-                                 double* __restrict__ ysym) {
+                                 const double* __restrict__ T, double* __restrict__ ysym) {
   int64_t pi = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (pi >= npair_pad) return;
   const bool valid = pi < npair;
@@ -34,20 +35,10 @@ __global__ void sym_basis_kernel(const double* __restrict__ x, const int* __rest
   const int64_t pg = pi >> 2;
   const int k = (int)(pi & 3);
   double* blk = ysym + pg * (2 * TBS * 16);
-  double pm1 = 1.0, pc = xv;
+  double q[KMAX];
+  basis_row<KMAX>(xv, K, norm, T, q);          // (T keeps the parity of a column: temx_plan_finalize)
   for (int l = 0; l < 8 * TBS; ++l) {
-    double P;
-    if (l == 0) {
-      P = 1.0;
-    } else if (l == 1) {
-      P = xv;
-    } else {
-      double pn = ((2 * l - 1) * xv * pc - (l - 1) * pm1) / l;
-      pm1 = pc;
-      pc = pn;
-      P = pn;
-    }
-    const double val = (valid && l < K) ? norm[l] * P : 0.0;
+    const double val = (valid && l < K) ? q[l] : 0.0;
     const int h = l >> 1;                       // index among the even (or odd) harmonics
     const int t = (l & 1) * TBS + (h >> 2);     // block: even blocks first, then odd
     blk[t * 16 + k * 4 + (h & 3)] = val;

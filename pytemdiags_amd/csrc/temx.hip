@@ -92,7 +92,14 @@ struct temx_plan {
   bool weighted = false;      // weights mode (temx_plan_set_weights): projection rows are scaled, reconstruction rows are not
   int rank = 0;               // numerical rank of Y0 (== K unless the pseudo-inverse fallback ran)
   DevBuf x, Y0, yblk, yblk_w, Y0p, G, Ginv, norm, flag;
-  DevBuf gblk, ypblk;            // Ginv / Y0p as 4x4 MFMA A-operand blocks (solve_mfma_kernel, K <= 64)
+  DevBuf gblk, ypblk;            // Ginv / Qp as 4x4 MFMA A-operand blocks (solve_mfma_kernel, K <= 64)
+  // Projection basis (temx_plan_finalize): qbasis = the sweeps project on Q = Y0 R^-1, R the Cholesky factor of
+  // the Gram matrix, T = R^-1 on the device.  Qp = Y0p T is the operand that takes coefficients to the output
+  // latitudes (Y0p itself stays the attribute), Ginv the inverse of the second Gram matrix Q^T Q (the identity up
+  // to rounding), GinvA = T T^T the inverse of the Gram matrix of Y0 (attributes Y0inv / sanity numbers only).
+  bool qbasis = false;
+  DevBuf T, Qp, GinvA, G2, xo, xc;
+  int64_t cls_npad = 0;
   const double* yproj_ptr() const { return yblk_w.p ? yblk_w.d() : yblk.d(); }
   std::vector<double> lat_out_deg;
   // TEM configuration
@@ -424,7 +431,7 @@ static int launch_solve(temx_plan* pl, const double* B, int NF, int64_t D, doubl
     static std::atomic<uint64_t> attr{0};
     if (int rc = lds_attr_once(attr, pl->device, reinterpret_cast<const void*>(solve_kernel), 160 * 1024)) return rc;
     hipLaunchKernelGGL(solve_kernel, grid, dim3(1024), slds, st, B, pl->K, pl->K4, pl->M, D, pl->Ginv.d(),
-                       pl->Y0p.d(), C, Xb);
+                       pl->Qp.d(), C, Xb);
   }
   HIPCHK(hipGetLastError());
   return TEMX_OK;
@@ -1040,8 +1047,10 @@ static int launch_eddy_sym_t(temx_plan* pl, const FieldPtrs<4>& fp, const double
 // ------------------------------------------------------------------------------------------------
 // host linear algebra: Cholesky inverse of the K x K Gram matrix (K <= 64)
 // ------------------------------------------------------------------------------------------------
-static int spd_inverse(const double* G, int K, double* Ginv) {
-  std::vector<long double> Lm((size_t)K * K, 0.0L), Li((size_t)K * K, 0.0L);
+// Li = L^-1 for G = L L^T (long double); -1 when G is not numerically positive definite
+static int spd_factor(const double* G, int K, std::vector<long double>& Li) {
+  std::vector<long double> Lm((size_t)K * K, 0.0L);
+  Li.assign((size_t)K * K, 0.0L);
   for (int i = 0; i < K; ++i) {
     for (int j = 0; j <= i; ++j) {
       long double s = G[i * K + j];
@@ -1064,13 +1073,17 @@ static int spd_inverse(const double* G, int K, double* Ginv) {
       Li[i * K + c] = s / Lm[i * K + i];
     }
   }
+  return 0;
+}
+
+// G^-1 = L^-T L^-1
+static void inverse_from_factor(const std::vector<long double>& Li, int K, double* Ginv) {
   for (int i = 0; i < K; ++i)
     for (int j = 0; j < K; ++j) {
       long double s = 0.0L;
       for (int k = std::max(i, j); k < K; ++k) s += Li[k * K + i] * Li[k * K + j];
       Ginv[i * K + j] = (double)s;
     }
-  return 0;
 }
 
 // Pseudo-inverse of the symmetric positive semi-definite Gram matrix by cyclic Jacobi rotations
@@ -1245,6 +1258,7 @@ void temx_plan_destroy(temx_plan* pl) {
   pl->pbuf.release();
   pl->gblk.release();
   pl->ypblk.release();
+  for (DevBuf* b : {&pl->T, &pl->Qp, &pl->GinvA, &pl->G2, &pl->xo, &pl->xc}) b->release();
   for (auto& kv : pl->csplits) kv.second.release();
   for (int w = 0; w < 2; ++w)
     for (auto& tl : pl->timed[w]) {
@@ -1254,11 +1268,72 @@ void temx_plan_destroy(temx_plan* pl) {
   delete pl;
 }
 
-static int build_basis(temx_plan* pl, const double* rowscale_dev, double* Y0, double* yblk) {
+// the basis kernels keep one row of K values per thread: 64 in registers, 512 (L <= 511) in scratch
+#define TEMX_BASIS(kern, K, ...)                          \
+  do {                                                    \
+    if ((K) <= 64)                                        \
+      hipLaunchKernelGGL(kern<64>, __VA_ARGS__);          \
+    else                                                  \
+      hipLaunchKernelGGL(kern<512>, __VA_ARGS__);         \
+  } while (0)
+
+// native rows: canonical [N][K] copy (Y0c, may be null) and the 4x4 blocks of the sweeps (yblk, may be null);
+// T: null for Y0 itself, or the device copy of R^-1 for the rows of Q = Y0 R^-1
+static int build_basis(temx_plan* pl, const double* rowscale_dev, const double* T, double* Y0c, double* yblk) {
   const int64_t npad = pl->nchunk * 16;
-  hipLaunchKernelGGL(basis_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, 0, pl->x.d(), pl->N,
-                     npad, pl->K, pl->stride, pl->norm.d(), rowscale_dev, Y0, yblk);
+  TEMX_BASIS(basis_kernel, pl->K, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, 0, pl->x.d(), pl->N, npad, pl->K,
+             pl->stride, pl->norm.d(), rowscale_dev, T, Y0c, yblk);
   HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+// rows at the output latitudes: canonical [M][K] into `dst`; for K <= 64 also the blocked copy of Qp
+static int build_out_basis(temx_plan* pl, const double* T, double* dst, bool blocks) {
+  const int64_t mch = (pl->M + 15) / 16;
+  TEMX_BASIS(basis_kernel, pl->K, dim3((unsigned)((mch * 16 + 255) / 256)), dim3(256), 0, 0, pl->xo.d(), (int64_t)pl->M,
+             mch * 16, pl->K, pl->stride, pl->norm.d(), (const double*)nullptr, T, dst, (double*)nullptr);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
+  if (blocks && pl->K <= 64) {   // blocked copy for solve_mfma_kernel
+    std::vector<double> yp((size_t)pl->M * pl->K);
+    HIPCHK(hipMemcpy(yp.data(), dst, yp.size() * 8, hipMemcpyDeviceToHost));
+    return upload_blocks(pl->ypblk, yp.data(), pl->M, pl->K, pl->TB);
+  }
+  return TEMX_OK;
+}
+
+// basis rows at the class latitudes (kernels_cls.hpp): ycls, or the 64-harmonic slices ycls_l
+static int build_cls_basis(temx_plan* pl, const double* T) {
+  const unsigned nb = (unsigned)((pl->cls_npad + 255) / 256);
+  if (pl->lcls) {
+    for (int sl = 0; sl < pl->nslice; ++sl)
+      TEMX_BASIS(cls_basis_slice_kernel, pl->K, dim3(nb), dim3(256), 0, 0, pl->xc.d(), pl->ncls, pl->cls_npad, pl->K,
+                 64 * sl, pl->norm.d(), T, pl->ycls_l.d() + sl * pl->ycls_lstride);
+  } else if (pl->cls) {
+    TEMX_BASIS(cls_basis_kernel, pl->K, dim3(nb), dim3(256), 0, 0, pl->xc.d(), pl->ncls, pl->cls_npad, pl->K, pl->TBS,
+               pl->norm.d(), T, pl->ycls.d());
+  }
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+static int build_sym_basis(temx_plan* pl, const double* T) {
+  if (!pl->sym) return TEMX_OK;
+  const int64_t n4 = pl->npg_alloc * 4;
+  TEMX_BASIS(sym_basis_kernel, pl->K, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, 0, pl->x.d(),
+             static_cast<const int*>(pl->rows.p), pl->npair, n4, pl->K, pl->TBS, pl->norm.d(), T, pl->ysym.d());
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+// every projection / reconstruction operand of the plan in the basis T (null: Y0 itself)
+static int build_all_bases(temx_plan* pl, const double* T) {
+  int rc;
+  if ((rc = build_basis(pl, nullptr, T, nullptr, pl->yblk.d()))) return rc;
+  if ((rc = build_cls_basis(pl, T))) return rc;
+  if ((rc = build_sym_basis(pl, T))) return rc;
+  if ((rc = build_out_basis(pl, T, pl->Qp.d(), true))) return rc;
+  HIPCHK(hipDeviceSynchronize());
   return TEMX_OK;
 }
 
@@ -1316,31 +1391,16 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
   // one extra chunk of blocks: the sweeps prefetch A operands one group / step ahead
   if ((rc = pl->yblk.ensure((size_t)(pl->nchunk + 1) * 4 * pl->stride * 16 * 8))) return bail(rc);
   if (hipMemset(pl->yblk.p, 0, pl->yblk.bytes) != hipSuccess) return bail(fail(TEMX_EHIP, "hipMemset of the Y0 blocks failed"));
-  if ((rc = build_basis(pl, nullptr, pl->Y0.d(), pl->yblk.d()))) return bail(rc);
+  if ((rc = build_basis(pl, nullptr, nullptr, pl->Y0.d(), pl->yblk.d()))) return bail(rc);
 
-  // Y0p on the output latitudes (sph_zonal_mean.py:367-370): same kernel, canonical copy only
-  {
-    DevBuf xo;
-    for (int m = 0; m < M; ++m) xs[m] = std::cos((90.0 - lat_out_deg_host[m]) * d2r);
-    if ((rc = upload(xo, xs.data(), (size_t)M * 8))) return bail(rc);
-    if ((rc = pl->Y0p.ensure((size_t)M * pl->K * 8))) {
-      xo.release();
-      return bail(rc);
-    }
-    const int64_t mch = (M + 15) / 16;
-    hipLaunchKernelGGL(basis_kernel, dim3((unsigned)((mch * 16 + 255) / 256)), dim3(256), 0, 0, xo.d(),
-                       (int64_t)M, mch * 16, pl->K, pl->stride, pl->norm.d(), (const double*)nullptr,
-                       pl->Y0p.d(), (double*)nullptr);
-    hipError_t e = hipDeviceSynchronize();
-    xo.release();
-    if (e != hipSuccess) return bail(fail(TEMX_EHIP, "basis kernel failed: %s", hipGetErrorString(e)));
-    if (pl->K <= 64) {   // blocked copy for solve_mfma_kernel
-      std::vector<double> yp((size_t)M * pl->K);
-      if (hipMemcpy(yp.data(), pl->Y0p.p, yp.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)
-        return bail(fail(TEMX_EHIP, "copy of Y0p failed"));
-      if ((rc = upload_blocks(pl->ypblk, yp.data(), M, pl->K, pl->TB))) return bail(rc);
-    }
-  }
+  // Y0p on the output latitudes (sph_zonal_mean.py:367-370): same kernel, canonical copies only (Y0p the
+  // attribute, Qp the device operand -- equal until temx_plan_finalize changes the basis)
+  for (int m = 0; m < M; ++m) xs[m] = std::cos((90.0 - lat_out_deg_host[m]) * d2r);
+  if ((rc = upload(pl->xo, xs.data(), (size_t)M * 8))) return bail(rc);
+  if ((rc = pl->Y0p.ensure((size_t)M * pl->K * 8))) return bail(rc);
+  if ((rc = pl->Qp.ensure((size_t)M * pl->K * 8))) return bail(rc);
+  if ((rc = build_out_basis(pl, nullptr, pl->Y0p.d(), false))) return bail(rc);
+  if ((rc = build_out_basis(pl, nullptr, pl->Qp.d(), true))) return bail(rc);
 
   // local Gram G = Y0^T Y0 through the projection sweep itself (A = Y0, D = K)
   {
@@ -1370,44 +1430,24 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
       if ((rc = upload(pl->crow, ct.crow.data(), ct.crow.size() * sizeof(int)))) return bail(rc);
 
       if ((rc = upload(pl->ccnt, ct.cnt.data(), ct.cnt.size() * 8))) return bail(rc);
-      DevBuf xc;
-      if ((rc = upload(xc, ct.xc.data(), ct.xc.size() * 8))) return bail(rc);
-      if (pl->large) {   // class sums first, sliced basis at the class latitudes (kernels_cls.hpp)
-        const int64_t npad = (ct.ngroups + 1) * 4;
-        pl->ycls_lstride = (ct.ngroups + 1) * 256;
-        rc = pl->ycls_l.ensure((size_t)pl->nslice * pl->ycls_lstride * 8);
-        if (rc) {
-          xc.release();
-          return bail(rc);
-        }
-        for (int sl = 0; sl < pl->nslice; ++sl)
-          hipLaunchKernelGGL(cls_basis_slice_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, 0, xc.d(),
-                             ct.ncls, npad, pl->K, 64 * sl, pl->norm.d(), pl->ycls_l.d() + sl * pl->ycls_lstride);
-        hipError_t e2 = hipDeviceSynchronize();
-        xc.release();
-        if (e2 != hipSuccess) return bail(fail(TEMX_EHIP, "class basis kernel failed: %s", hipGetErrorString(e2)));
-        pl->gbatch0 = std::move(ct.gbatch0);
-        pl->cgroups = ct.ngroups;
-        pl->cbatches = ct.nbatch;
-        pl->ncls = ct.ncls;
-        pl->lcls = true;
-      } else {
-      rc = pl->ycls.ensure((size_t)(ct.ngroups + 1) * 2 * pl->TBS * 16 * 8);
-      if (rc) {
-        xc.release();
-        return bail(rc);
-      }
-      const int64_t npad = (ct.ngroups + 1) * 4;
-      hipLaunchKernelGGL(cls_basis_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, 0, xc.d(), ct.ncls,
-                         npad, pl->K, pl->TBS, pl->norm.d(), pl->ycls.d());
-      hipError_t e2 = hipDeviceSynchronize();
-      xc.release();
-      if (e2 != hipSuccess) return bail(fail(TEMX_EHIP, "class basis kernel failed: %s", hipGetErrorString(e2)));
+      if ((rc = upload(pl->xc, ct.xc.data(), ct.xc.size() * 8))) return bail(rc);
+      pl->cls_npad = (ct.ngroups + 1) * 4;
       pl->gbatch0 = std::move(ct.gbatch0);
       pl->cgroups = ct.ngroups;
       pl->cbatches = ct.nbatch;
       pl->ncls = ct.ncls;
-      pl->cls = true;
+      if (pl->large) {   // class sums first, sliced basis at the class latitudes (kernels_cls.hpp)
+        pl->ycls_lstride = (ct.ngroups + 1) * 256;
+        if ((rc = pl->ycls_l.ensure((size_t)pl->nslice * pl->ycls_lstride * 8))) return bail(rc);
+        pl->lcls = true;
+      } else {
+        if ((rc = pl->ycls.ensure((size_t)(ct.ngroups + 1) * 2 * pl->TBS * 16 * 8))) return bail(rc);
+        pl->cls = true;
+      }
+      if ((rc = build_cls_basis(pl, nullptr))) return bail(rc);
+      {
+        hipError_t e2 = hipDeviceSynchronize();
+        if (e2 != hipSuccess) return bail(fail(TEMX_EHIP, "class basis kernel failed: %s", hipGetErrorString(e2)));
       }
     }
   }
@@ -1428,12 +1468,10 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
       }
       if ((rc = upload(pl->rows, rows.data(), rows.size() * sizeof(int)))) return bail(rc);
       if ((rc = pl->ysym.ensure((size_t)pl->npg_alloc * 2 * pl->TBS * 16 * 8))) return bail(rc);
-      hipLaunchKernelGGL(sym_basis_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, 0, pl->x.d(),
-                         static_cast<const int*>(pl->rows.p), pl->npair, n4, pl->K, pl->TBS, pl->norm.d(),
-                         pl->ysym.d());
+      pl->sym = true;
+      if ((rc = build_sym_basis(pl, nullptr))) return bail(rc);
       hipError_t e2 = hipDeviceSynchronize();
       if (e2 != hipSuccess) return bail(fail(TEMX_EHIP, "sym basis kernel failed: %s", hipGetErrorString(e2)));
-      pl->sym = true;
     }
   }
   if (!(flags & TEMX_DEFER_FINALIZE)) {
@@ -1453,6 +1491,35 @@ int temx_plan_one_pass(const temx_plan* pl) {
   return pl && ((pl->cls && pl->onepass) || (pl->lcls && pl->lone)) ? 1 : 0;
 }
 
+// G2 (device) = Q^T Q over this plan's rows, through the projection sweep (A = Q, D = K)
+static int gram_of_q(temx_plan* pl) {
+  DevBuf Qc;
+  int rc = Qc.ensure((size_t)pl->N * pl->K * 8);
+  if (rc) return rc;
+  if ((rc = pl->G2.ensure((size_t)pl->K * pl->K * 8)) == TEMX_OK &&
+      (rc = build_basis(pl, nullptr, pl->T.d(), Qc.d(), nullptr)) == TEMX_OK) {
+    Split sp = choose_split(pl->K, pl->nchunk, 2 * pl->num_cu);
+    FieldPtrs<1> fp;
+    fp.p[0] = Qc.p;
+    rc = project_all<1>(pl, fp, TEMX_F64, pl->K, nullptr, -1, sp, pl->G2.d(), 0);
+  }
+  hipError_t e = hipDeviceSynchronize();
+  Qc.release();
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(TEMX_EHIP, "gram kernel failed: %s", hipGetErrorString(e));
+  return TEMX_OK;
+}
+
+// Replaces lstsq(Y0, I_N) (sph_zonal_mean.py:389).  The Gram matrix G = Y0^T Y0 squares the condition
+// number of Y0, and multiplying by an explicit G^-1 squares it once more (measured on a random grid with
+// cond(G) = 5.9e3: 1.4e-9 from the reference's SVD solution, profiles/r02_fuzz_seed_887.log).  So the plan
+// re-orthogonalises (Cholesky-QR2): R from the Cholesky factorisation of G (long double), every basis block
+// of the sweeps rebuilt for Q = Y0 R^-1 -- a row of Q still depends on latitude only, and with an
+// equatorially symmetric grid R does not mix even and odd harmonics, so the class / paired sweeps keep
+// working -- then the Gram matrix of Q (the identity up to cond(G) eps) factorised once more
+// (temx_plan_refine).  The sweeps project on Q, the K x K "solve" multiplies by (Q^T Q)^-1 ~ I, and Qp = Y0p
+// R^-1 takes the coefficients to the output latitudes: errors of order cond(Y0) eps.  Attributes (Y0, Y0p,
+// Y0inv = G^-1 Y0^T) are unchanged.  TEMX_NO_QR=1 keeps the plain normal equations (A/B runs).
 int temx_plan_finalize(temx_plan* pl, const double* G_host) {
   if (!pl) return fail(TEMX_EINVAL, "null plan");
   HIPCHK(hipSetDevice(pl->device));
@@ -1466,20 +1533,84 @@ int temx_plan_finalize(temx_plan* pl, const double* G_host) {
   }
   for (double v : G)
     if (!std::isfinite(v)) return fail(TEMX_EINVAL, "Gram matrix is not finite (NaN latitudes?)");
-  if (spd_inverse(G.data(), K, Gi.data()) != 0) {
+  if (pl->qbasis) {               // finalised before: back to the Y0 basis the Gram matrix refers to
+    if (int rcb = build_all_bases(pl, nullptr)) return rcb;
+    pl->qbasis = false;
+  }
+  // On an equatorially symmetric grid G[l][m] vanishes for l + m odd; the entries that rounding left
+  // there are cleared, so that R (and Q) keep the parity the class / paired sweeps rely on.
+  const bool parity_paths = pl->sym || pl->cls || pl->lcls;
+  double odd_max = 0.0, diag_max = 0.0;
+  for (int i = 0; i < K; ++i) {
+    diag_max = std::max(diag_max, std::fabs(G[(size_t)i * K + i]));
+    for (int j = 0; j < K; ++j)
+      if ((i + j) & 1) odd_max = std::max(odd_max, std::fabs(G[(size_t)i * K + j]));
+  }
+  const bool checker = odd_max <= 1e-10 * diag_max;
+  if (parity_paths && checker)
+    for (int i = 0; i < K; ++i)
+      for (int j = 0; j < K; ++j)
+        if ((i + j) & 1) G[(size_t)i * K + j] = 0.0;
+  std::vector<long double> Li;
+  const bool spd = spd_factor(G.data(), K, Li) == 0;
+  if (!spd) {
     // rank-deficient Y0: pseudo-inverse, like the reference's lstsq (sph_zonal_mean.py:389)
     int rank = 0;
     if (sym_pinv(G.data(), K, Gi.data(), &rank) != 0 || rank == 0)
       return fail(TEMX_ERANK, "Y0^T Y0 has no positive eigenvalue (N=%lld, K=%d)", (long long)pl->N, K);
     pl->rank = rank;
   } else {
+    inverse_from_factor(Li, K, Gi.data());
     pl->rank = K;
   }
-  if (int rcg = set_ginv(pl, Gi.data())) return rcg;
+  if (int rca = upload(pl->GinvA, Gi.data(), Gi.size() * 8)) return rca;
+  static const bool no_qr = [] { const char* e = getenv("TEMX_NO_QR"); return e && e[0] == '1'; }();
+  const bool want_q = spd && !no_qr && (!parity_paths || checker);
+  if (want_q) {
+    std::vector<double> T((size_t)K * K, 0.0), I((size_t)K * K, 0.0);
+    for (int l = 0; l < K; ++l) {
+      I[(size_t)l * K + l] = 1.0;
+      for (int j = l; j < K; ++j) T[(size_t)l * K + j] = (double)Li[(size_t)j * K + l];   // R^-1 = (L^-1)^T
+    }
+    if (int rct = upload(pl->T, T.data(), T.size() * 8)) return rct;
+    if (int rcb = build_all_bases(pl, pl->T.d())) return rcb;
+    pl->qbasis = true;
+    if (int rcg = set_ginv(pl, I.data())) return rcg;      // until temx_plan_refine
+  } else {
+    if (int rcg = set_ginv(pl, Gi.data())) return rcg;
+  }
   int zero = 0;
   HIPCHK(hipMemcpy(pl->flag.p, &zero, sizeof(int), hipMemcpyHostToDevice));
   pl->finalized = true;
+  pl->op_valid = pl->c4_valid = pl->xb_valid = pl->tq_valid = false;   // sums / coefficients of another basis
+  // one process owns all the rows: second pass of the re-orthogonalisation with its own Gram matrix of Q
+  if (want_q && !G_host) return temx_plan_refine(pl, nullptr);
   return TEMX_OK;
+}
+
+int temx_plan_refine(temx_plan* pl, const double* G2_host) {
+  if (!pl) return fail(TEMX_EINVAL, "null plan");
+  if (!pl->finalized) return fail(TEMX_ESTATE, "plan not finalised");
+  if (!pl->qbasis) return TEMX_OK;                 // normal equations / pseudo-inverse / weights: nothing to refine
+  HIPCHK(hipSetDevice(pl->device));
+  const int K = pl->K;
+  std::vector<double> G2((size_t)K * K), Gi((size_t)K * K);
+  if (G2_host) {
+    std::copy(G2_host, G2_host + (size_t)K * K, G2.begin());
+  } else {
+    if (int rc = gram_of_q(pl)) return rc;
+    HIPCHK(hipMemcpy(G2.data(), pl->G2.p, G2.size() * 8, hipMemcpyDeviceToHost));
+  }
+  for (double v : G2)
+    if (!std::isfinite(v)) return fail(TEMX_EINVAL, "second Gram matrix is not finite");
+  if (pl->sym || pl->cls || pl->lcls)              // same parity argument as in temx_plan_finalize
+    for (int i = 0; i < K; ++i)
+      for (int j = 0; j < K; ++j)
+        if ((i + j) & 1) G2[(size_t)i * K + j] = 0.0;
+  std::vector<long double> Li;
+  if (spd_factor(G2.data(), K, Li) != 0) return TEMX_OK;   // (cannot happen for Q^T Q ~ I; keep the identity)
+  inverse_from_factor(Li, K, Gi.data());
+  return set_ginv(pl, Gi.data());
 }
 
 int temx_plan_set_weights(temx_plan* pl, const double* w_host) {
@@ -1489,6 +1620,10 @@ int temx_plan_set_weights(temx_plan* pl, const double* w_host) {
   // and make the "Gram inverse" the identity.
   std::vector<double> w((size_t)pl->N);
   for (int64_t i = 0; i < pl->N; ++i) w[i] = w_host[i] * 4.0 * M_PI;
+  if (pl->qbasis) {               // finalised before: the weighted operator works in the Y0 basis
+    if (int rcb = build_all_bases(pl, nullptr)) return rcb;
+    pl->qbasis = false;
+  }
   DevBuf wd;
   int rc = upload(wd, w.data(), w.size() * 8);
   if (rc) return rc;
@@ -1498,7 +1633,7 @@ int temx_plan_set_weights(temx_plan* pl, const double* w_host) {
     return rc;
   }
   (void)hipMemset(pl->yblk_w.p, 0, pl->yblk_w.bytes);
-  rc = build_basis(pl, wd.d(), nullptr, pl->yblk_w.d());
+  rc = build_basis(pl, wd.d(), nullptr, nullptr, pl->yblk_w.d());
   hipError_t e = hipDeviceSynchronize();
   wd.release();
   if (rc) return rc;
@@ -1506,6 +1641,7 @@ int temx_plan_set_weights(temx_plan* pl, const double* w_host) {
   std::vector<double> I((size_t)pl->K * pl->K, 0.0);
   for (int k = 0; k < pl->K; ++k) I[(size_t)k * pl->K + k] = 1.0;
   if (int rcg = set_ginv(pl, I.data())) return rcg;
+  if (int rca = upload(pl->GinvA, I.data(), I.size() * 8)) return rca;
   // weighted rows of one latitude no longer share a basis row: every latitude-structured path is off
   // (the large-L class path too: its class basis ycls_l is unweighted)
   pl->sym = pl->cls = pl->lcls = false;
@@ -1533,14 +1669,29 @@ int temx_get_matrix(temx_plan* pl, int which, double* dst, void* stream) {
       return TEMX_OK;
     case TEMX_MAT_GINV:
       if (!pl->finalized) return fail(TEMX_ESTATE, "plan not finalised");
-      HIPCHK(hipMemcpyAsync(dst, pl->Ginv.p, KK, hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemcpyAsync(dst, pl->GinvA.p, KK, hipMemcpyDeviceToDevice, st));
       return TEMX_OK;
     case TEMX_MAT_Y0INV:
       if (!pl->finalized) return fail(TEMX_ESTATE, "plan not finalised");
       hipLaunchKernelGGL(y0inv_kernel, dim3((unsigned)((pl->N + 255) / 256)), dim3(256), 0, st, pl->Y0.d(),
-                         pl->Ginv.d(), pl->N, pl->K, dst);
+                         pl->GinvA.d(), pl->N, pl->K, dst);
       HIPCHK(hipGetLastError());
       return TEMX_OK;
+    case TEMX_MAT_GRAM2: {
+      // this rank's share of Q^T Q (ncol-sharded callers all-reduce it and hand it to temx_plan_refine);
+      // the identity when the plan does not run on a re-orthogonalised basis
+      if (!pl->finalized) return fail(TEMX_ESTATE, "plan not finalised");
+      if (!pl->qbasis) {
+        std::vector<double> I((size_t)pl->K * pl->K, 0.0);
+        for (int k = 0; k < pl->K; ++k) I[(size_t)k * pl->K + k] = 1.0;
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipMemcpy(dst, I.data(), KK, hipMemcpyHostToDevice));
+        return TEMX_OK;
+      }
+      if (int rc2 = gram_of_q(pl)) return rc2;
+      HIPCHK(hipMemcpyAsync(dst, pl->G2.p, KK, hipMemcpyDeviceToDevice, st));
+      return TEMX_OK;
+    }
     default:
       return fail(TEMX_EINVAL, "unknown matrix id %d", which);
   }

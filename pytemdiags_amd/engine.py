@@ -104,6 +104,16 @@ class Plan:
             assert g.shape == (self.K, self.K)
             check(self.lib.temx_plan_finalize(self._h, pg))
 
+    def refine(self, G2=None):
+        """Second pass of the re-orthogonalisation (temx_plan_refine): ``G2`` the all-reduced
+        ``matrix(MAT_GRAM2)`` of an ncol-sharded job, or None for this plan's own rows."""
+        if G2 is None:
+            check(self.lib.temx_plan_refine(self._h, None))
+        else:
+            g, pg = _dbl(G2)
+            assert g.shape == (self.K, self.K)
+            check(self.lib.temx_plan_refine(self._h, pg))
+
     def set_weights(self, weights):
         w, pw = _dbl(weights)
         assert w.size == self.N
@@ -112,6 +122,7 @@ class Plan:
     def matrix(self, which):
         shape = {_lib.MAT_Y0: (self.N, self.K), _lib.MAT_Y0P: (self.M, self.K),
                  _lib.MAT_GRAM: (self.K, self.K), _lib.MAT_GINV: (self.K, self.K),
+                 _lib.MAT_GRAM2: (self.K, self.K),
                  _lib.MAT_Y0INV: (self.K, self.N)}[which]
         out = torch.empty(shape, dtype=torch.float64, device=self.device)
         check(self.lib.temx_get_matrix(self._h, which, _ptr(out), self._stream()))

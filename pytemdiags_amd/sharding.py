@@ -7,7 +7,7 @@ Two ways the path shards:
 * **ncol sharding** -- rows split in blocks (whole latitude classes per rank, see
   ``symmetric_ncol_shards``); the only cross-row reduction is the
   projection ``Y0^T A``, so each rank computes partial sums over its rows and the ranks
-  all-reduce (i) the K x K Gram matrix once at plan build, (ii) the [4][K][D] sums of
+  all-reduce (i) the K x K Gram matrix (and the Gram matrix of the re-orthogonalised basis) once at plan build, (ii) the [4][K][D] sums of
   (u, v, theta, omega) and (iii) the [3][K][D] sums of the eddy products -- one fused message
   each.  Every rank then solves the K x K system and evaluates the (tiny) zonal-grid epilogue
   redundantly.
@@ -22,7 +22,7 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
-MAT_GRAM = 2
+MAT_GRAM, MAT_GRAM2 = 2, 5
 
 
 def shard_bounds(n, world, rank):
@@ -79,6 +79,10 @@ class NcolShardedTEM:
         G = backend.matrix(MAT_GRAM)
         allreduce_sum_(G, group)                       # (i) Gram matrix, K x K, once
         backend.finalize(G.detach().cpu().numpy())
+        if hasattr(backend, "refine"):                 # (i') second pass of the re-orthogonalisation (temx.h)
+            G2 = backend.matrix(MAT_GRAM2)
+            allreduce_sum_(G2, group)
+            backend.refine(G2.detach().cpu().numpy())
 
     def run(self, ua, va, ta, wap, want_zonal=False):
         be = self.backend

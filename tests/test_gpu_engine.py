@@ -32,7 +32,9 @@ def load(name):
 
 
 def test_mfma_layout_project_asymmetric(eng):
-    """Y0^T A against numpy on asymmetric random data, ragged N and D (fragment-layout check)."""
+    """The projection sweep against numpy on asymmetric random data, ragged N and D (fragment-layout check).
+    A finalised plan projects on Q = Y0 R^-1 (include/temx.h, temx_plan_finalize): B = Q^T A.  Projecting Y0
+    itself gives Q^T Y0 = R^-T G = R, so R^T B must equal Y0^T A."""
     from oracle import tem_oracle as orc
     rng = np.random.default_rng(0)
     for N, D, L in [(1000, 37, 50), (866, 1, 50), (2500, 72, 20), (333, 130, 63), (64, 16, 3),
@@ -50,9 +52,19 @@ def test_mfma_layout_project_asymmetric(eng):
         B = plan.project(dev(A)).cpu().numpy()
         ref = Y0d.T @ A
         assert B.shape == ref.shape
-        assert np.max(np.abs(B - ref)) <= 1e-12 * np.max(np.abs(ref)) * np.sqrt(N), (N, D, L)
         G = plan.matrix(2).cpu().numpy()
         assert np.max(np.abs(G - Y0d.T @ Y0d)) <= 1e-12 * np.max(np.abs(G))
+        R = plan.project(dev(Y0d)).cpu().numpy()            # the plan's Cholesky factor (identity basis: G)
+        if os.environ.get("TEMX_NO_QR") == "1":
+            assert np.max(np.abs(R - G)) <= 1e-12 * np.max(np.abs(G)) * np.sqrt(N)
+            back = B
+        else:
+            assert np.max(np.abs(np.tril(R, -1))) <= 1e-11 * np.max(np.abs(R)), (N, D, L)
+            assert np.max(np.abs(R.T @ R - G)) <= 1e-11 * np.max(np.abs(G)), (N, D, L)
+            back = R.T @ B
+            G2 = plan.matrix(5).cpu().numpy()                # Q^T Q: the identity to cond(G) eps
+            assert np.max(np.abs(G2 - np.eye(L + 1))) <= 1e-13 * np.linalg.cond(G) + 1e-12, (N, D, L)
+        assert np.max(np.abs(back - ref)) <= 1e-12 * np.max(np.abs(ref)) * np.sqrt(N) * max(1.0, np.linalg.cond(R) / 50), (N, D, L)
         plan.close()
 
 
