@@ -323,12 +323,15 @@ def test_weights_mode_tem_pipeline_on_a_class_grid(eng, L):
     assert plan.sweep_mode == 0 and not plan.one_pass
     res, zon = plan.tem_run(*[dev(x) for x in f], want_zonal=True)
     assert not plan.status()
-    for i, n in enumerate(_lib.ZONAL_NAMES[:7]):
+    # measured (tools/weighted_probe.py, profiles/r03_weighted_probe.log): zonal means and intermediates
+    # <= 3e-12, the ten results <= 8e-14 on this grid -- the plain fp64 tolerance holds for all of them
+    # (round 2 held the results to 1e-9 only)
+    for i, n in enumerate(_lib.ZONAL_NAMES):
         e = fieldnorm_err(zon[i].cpu().numpy(), getattr(ref, n))
         assert e <= TOL64, (n, e)
     for i, n in enumerate(_lib.RESULT_NAMES):
         e = fieldnorm_err(res[i].cpu().numpy(), getattr(ref, n)())
-        assert e <= 1e-9, (n, e)      # psi = vptpb / dthetab_dp amplifies on this coarse 64 x 16 grid
+        assert e <= TOL64, (n, e)
     plan.close()
 
 
