@@ -721,6 +721,12 @@ flux_cls_kernel(int64_t D, int K, int K4, const double* __restrict__ ycls, const
   }
 }
 
+// Tried and measured, not kept (round 3): the same phase with the 4 x 14 coefficient operands of a d-tile in
+// REGISTERS (one wave per SIMD, 244 VGPR + 100 AGPR, LDS serving only the 2 x 14 Y operands of a group).
+// flux_cls_kernel reads one LDS operand per reconstruction MFMA and its LDS traffic (43 KB per class-group
+// and d-tile) takes about as long as its MFMAs at two waves per SIMD -- 1.79 ms on ne120 x 72 x 30 against
+// an MFMA bound of 1.05 ms -- but the register form ran at 2.02 ms: a single in-order wave does not overlap
+// its loads, LDS staging and product arithmetic with the matrix pipe (profiles/r03_ab_flux_registers.log).
 // ------------------------------------------------------------------------------------------------
 // Large-L class path (64 < K <= 256 on a grid with latitude classes): the class sums do not depend on
 // L, so the fields are swept once (project_cls_kernel<.., OP, PROJ = false>) and everything else
