@@ -251,6 +251,18 @@ int temx_tracer_stage1_sums(temx_plan* plan, const void* q, const void* va, cons
 int temx_tracer_stage2_from_sums(temx_plan* plan, const double* Bq, double* Bq2, void* stream);
 int temx_tracer_run(temx_plan* plan, const void* q, const void* va, const void* wap, int dtype,
                     double* tres, double* tzon, void* stream);
+/* TEM and ONE tracer that is known up front (TEMDiagnostics(q=...), tem_diagnostics.py:241-259 runs both in
+ * its constructor): temx_tem_tracer_stage1 is temx_tem_stage1 + temx_tracer_stage1_sums in ONE sweep over
+ * (u, v, T, omega, q) -- 40 bytes per grid point instead of 32 + 24 -- with the four waves of a workgroup
+ * sharing a d-tile (ten projections).  Needs the one-pass class path (TEMX_ESTATE otherwise); q has the
+ * dtype of the fields.  Follow with temx_tem_stage2_from_sums, temx_tem_stage3, temx_tracer_stage2_from_sums,
+ * temx_tracer_stage3 (B4, Bq are the all-reduce payloads when ncol-sharded).  temx_tem_tracer_run does all of
+ * that with plan-owned sums, and on any other path runs temx_tem_run and temx_tracer_run one after the other. */
+int temx_tem_tracer_stage1(temx_plan* plan, const void* ua, const void* va, const void* ta, const void* wap,
+                           const void* q, int dtype, double* B4, double* Bq, void* stream);
+int temx_tem_tracer_run(temx_plan* plan, const void* ua, const void* va, const void* ta, const void* wap,
+                        const void* q, int dtype, double* results, double* zonal, double* tres, double* tzon,
+                        void* stream);
 /* lazily materialise qp, qpvp, qpwapp ([ncol][D] fp64 each; NULL entries skipped) of the tracer
  * whose temx_tracer_stage2 / run was the last one on this plan (tem_diagnostics.py:537, 563-567). */
 int temx_tracer_eddy(temx_plan* plan, const void* q, const void* va, const void* wap, int dtype,

@@ -63,6 +63,8 @@ SIGNATURES = [
     ("temx_tracer_stage1_sums", _i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     ("temx_tracer_stage2_from_sums", _i, [_vp, _vp, _vp, _vp]),
     ("temx_tracer_run", _i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    ("temx_tem_tracer_stage1", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    ("temx_tem_tracer_run", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     ("temx_tracer_eddy", _i, [_vp, _vp, _vp, _vp, _i, C.POINTER(_vp), _vp]),
     ("temx_status", _i, [_vp, C.POINTER(_i), _vp]),
     ("temx_synth_fields", _i, [_i, _i64, _i, _i64, _i64, _vp, _vp, _vp, _i, _u64, _vp, _vp, _vp, _vp, _vp]),

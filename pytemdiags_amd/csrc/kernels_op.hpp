@@ -26,16 +26,25 @@ namespace temx {
 // KIND 0: TEM     fields (u, v, T -> theta, omega); stored sums of all four; co-moments u v, u omega, v theta
 // KIND 1: tracer  fields (q, v, omega); stored sum of q only (those of v and omega are in the TEM run's
 //                 csum); co-moments q v, q omega   (tem_diagnostics.py:532-538, 560-570)
+// KIND 2: TEM + one tracer in one sweep (kernels_op2.hpp, sweep_opw_kernel only): fields (u, v, T -> theta, omega, q);
+//                 stored sums: the four TEM ones (csum) and q's (csq); co-moments u v, u omega, v theta, q v, q omega
+// NPTR: field pointers handed over; TF / TQ: index of theta among the stored sums / of the v theta co-moment (-1: none);
+// NSTA: pairs of a class-sum record in `csum` (the remaining NST - NSTA go to records of `csq`)
 template <int KIND> struct OpKind;
 template <> struct OpKind<0> {
-  static constexpr int NFLD = 4, NST = 4, NQ = 3, WPS = 1;
+  static constexpr int NFLD = 4, NST = 4, NQ = 3, WPS = 1, NPTR = 4, TF = 2, TQ = 2, NSTA = 4;
   __host__ __device__ static constexpr int pa(int k) { return k == 2 ? 1 : 0; }              // u u v
   __host__ __device__ static constexpr int pb(int k) { return k == 0 ? 1 : (k == 1 ? 3 : 2); }   // v w theta
 };
 template <> struct OpKind<1> {
-  static constexpr int NFLD = 3, NST = 1, NQ = 2, WPS = 2;
+  static constexpr int NFLD = 3, NST = 1, NQ = 2, WPS = 2, NPTR = 4, TF = -1, TQ = -1, NSTA = 1;
   __host__ __device__ static constexpr int pa(int) { return 0; }                              // q q
   __host__ __device__ static constexpr int pb(int k) { return k == 0 ? 1 : 2; }               // v w
+};
+template <> struct OpKind<2> {
+  static constexpr int NFLD = 5, NST = 5, NQ = 5, WPS = 1, NPTR = 5, TF = 2, TQ = 2, NSTA = 4;
+  __host__ __device__ static constexpr int pa(int k) { return k == 2 ? 1 : (k >= 3 ? 4 : 0); }                // u u v q q
+  __host__ __device__ static constexpr int pb(int k) { return k == 0 ? 1 : (k == 1 ? 3 : (k == 2 ? 2 : (k == 3 ? 1 : 3))); }   // v w theta v w
 };
 
 template <typename T, int TBS, int PD, int KIND>

@@ -59,12 +59,16 @@ __device__ __forceinline__ void opw_round(const OpwSlot<NA, 2 * TBS>* slots, int
 // shared d-tile, 8-byte loads (row table crow of kernels_cls.hpp)
 // csplit holds 4 * nsplit + 1 group-aligned cuts: workgroup `split` owns pieces 4 split .. 4 split + 3
 // ------------------------------------------------------------------------------------------------
+// KIND 2 (TEM + one tracer, 10 projections, 5 fields): one wave per SIMD; the tracer's class sums go to csq.
+#ifndef TEMX_OPW_WPS
+#define TEMX_OPW_WPS 2
+#endif
 template <typename T, int TBS, int PD, int KIND>
-__global__ void __launch_bounds__(256, 2)
-sweep_opw_kernel(FieldPtrs<4> fp, int64_t D, int K, const double* __restrict__ ycls,
+__global__ void __launch_bounds__(256, KIND == 2 ? 1 : TEMX_OPW_WPS)
+sweep_opw_kernel(FieldPtrs<OpKind<KIND>::NPTR> fp, int64_t D, int K, const double* __restrict__ ycls,
                  const int4* __restrict__ crow, const int2* __restrict__ csplit,
                  const double* __restrict__ colscale, double* __restrict__ partial, int nsplit, int ndt,
-                 double* __restrict__ csum) {
+                 double* __restrict__ csum, double* __restrict__ csq) {
   using KD = OpKind<KIND>;
   constexpr int NB = 2 * TBS;
   constexpr int YE = NB * 16;
@@ -96,7 +100,7 @@ sweep_opw_kernel(FieldPtrs<4> fp, int64_t D, int K, const double* __restrict__ y
   const int par = wave >> 1;
   const int t0 = par * TBS + (wave & 1) * NBW, nbw = (wave & 1) ? TBS - NBW : NBW;
   const uint32_t yoff = (uint32_t)(g * 4 + (lane & 3));
-  const double sth = (KIND == 0 && colscale != nullptr) ? colscale[dcl] : 1.0;
+  const double sth = (KD::TF >= 0 && colscale != nullptr) ? colscale[dcl] : 1.0;
   const T* fb[NFLD];
 #pragma unroll
   for (int f = 0; f < NFLD; ++f) fb[f] = reinterpret_cast<const T*>(fp.p[f]) + dcl;
@@ -206,14 +210,19 @@ sweep_opw_kernel(FieldPtrs<4> fp, int64_t D, int K, const double* __restrict__ y
       else
         finish_side(sS, qS);
       north_open = false;
-      if (KIND == 0) {
-        sN[NST > 2 ? 2 : 0] *= sth; sS[NST > 2 ? 2 : 0] *= sth;
-        qN[NQ - 1] *= sth; qS[NQ - 1] *= sth;
+      if constexpr (KD::TF >= 0) {            // T -> theta: its sum and the v theta co-moment
+        sN[KD::TF] *= sth; sS[KD::TF] *= sth;
+        qN[KD::TQ] *= sth; qS[KD::TQ] *= sth;
       }
       if (dvalid) {
-        double2* o = reinterpret_cast<double2*>(csum + TEMX_CSUM_REC(grp, dt, ndt) * (2 * NST) * 64) + lane;
+        double2* o = reinterpret_cast<double2*>(csum + TEMX_CSUM_REC(grp, dt, ndt) * (2 * KD::NSTA) * 64) + lane;
 #pragma unroll
-        for (int f = 0; f < NST; ++f) TEMX_CSTORE(o + f * 64, make_double2(sN[f], sS[f]));
+        for (int f = 0; f < KD::NSTA; ++f) TEMX_CSTORE(o + f * 64, make_double2(sN[f], sS[f]));
+        if constexpr (NST > KD::NSTA) {       // the tracer's own records
+          double2* oq = reinterpret_cast<double2*>(csq + TEMX_CSUM_REC(grp, dt, ndt) * (2 * (NST - KD::NSTA)) * 64) + lane;
+#pragma unroll
+          for (int f = KD::NSTA; f < NST; ++f) TEMX_CSTORE(oq + (f - KD::NSTA) * 64, make_double2(sN[f], sS[f]));
+        }
       }
       ++grp;
       load_ys(grp);

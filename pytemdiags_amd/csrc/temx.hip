@@ -19,6 +19,7 @@
 #include "kernels_sym.hpp"
 #include "kernels_cls.hpp"
 #include "kernels_op.hpp"
+#include "kernels_op2.hpp"
 
 using namespace temx;
 
@@ -125,6 +126,7 @@ struct temx_plan {
   DevBuf crow, ycls;
   std::map<int, DevBuf> csplits;       // work cuts per number of pieces
   Split sp_cproj4, sp_cproj1, sp_ceddy, sp_cflux;
+  Split sp_copw;                 // TEM + tracer in one sweep (sweep_opw_kernel<.., 2>): one d-tile per workgroup
   // one-pass form of the class path: sweep 1 also stores per-class sums of products (csum), the
   // flux kernel replaces sweep 2 (kernels_cls.hpp)
   // large-L class path (64 < K <= 256 with latitude classes): class sums first, then sliced work on the sums
@@ -627,6 +629,41 @@ static bool build_classes(const double* lat, int64_t N, ClassTables& ct) {
   if ((double)N < 3.0 * (double)cls.size()) return false;   // < 3 columns per class: not worth it
   constexpr int MB = CLS_MB;
   auto nb = [](size_t m) { return (int)((m + MB - 1) / MB); };
+  // Outsized classes are cut into several classes at the same latitude.  Any subset of the columns of a
+  // latitude is a class (the algebra of kernels_cls.hpp holds per class side), and a class-group is the unit of
+  // work between two hand-overs of the shared-d-tile sweep and of the work cuts: the cubed sphere has ONE
+  // class of 1440 equator columns (360 batches) among 48 000 of 8 + 8 (4 batches), and every workgroup that
+  // met it ran 20 % longer -- all of them on one XCD (ne120 x 72 x 30, TEM + tracer sweep: 17.6 -> 14 ms).
+  {
+    std::map<std::pair<size_t, size_t>, size_t> hist;
+    for (const Cls& c : cls) ++hist[{c.n.size(), c.s.size()}];
+    std::pair<size_t, size_t> typ{0, 0};
+    size_t best = 0;
+    for (const auto& kv : hist)
+      if (kv.second > best) {
+        best = kv.second;
+        typ = kv.first;
+      }
+    const size_t cap_n = std::max<size_t>(typ.first, MB), cap_s = std::max<size_t>(typ.second, MB);
+    const int typ_b = std::max(1, nb(typ.first) + nb(typ.second));
+    std::vector<Cls> out;
+    out.reserve(cls.size());
+    for (Cls& c : cls) {
+      if (nb(c.n.size()) + nb(c.s.size()) <= 4 * typ_b) {
+        out.push_back(std::move(c));
+        continue;
+      }
+      const size_t parts = std::max((c.n.size() + cap_n - 1) / cap_n, (c.s.size() + cap_s - 1) / cap_s);
+      for (size_t k = 0; k < parts; ++k) {
+        Cls d;
+        d.alat = c.alat;
+        for (size_t m = k * cap_n; m < std::min((k + 1) * cap_n, c.n.size()); ++m) d.n.push_back(c.n[m]);
+        for (size_t m = k * cap_s; m < std::min((k + 1) * cap_s, c.s.size()); ++m) d.s.push_back(c.s[m]);
+        if (!d.n.empty() || !d.s.empty()) out.push_back(std::move(d));
+      }
+    }
+    cls.swap(out);
+  }
   // equal member counts inside a class-group; then by first row (some streaming order)
   std::stable_sort(cls.begin(), cls.end(), [&](const Cls& a, const Cls& b) {
     const int an = nb(a.n.size()), as = nb(a.s.size()), bn = nb(b.n.size()), bs = nb(b.s.size());
@@ -808,6 +845,28 @@ static int launch_sweep_op_t(temx_plan* pl, const FieldPtrs<4>& fp, double* part
     default: TEMX_LSO(8); break;
   }
 #undef TEMX_LSO
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+// TEM + one tracer in one sweep (kernels_op2.hpp): (u, v, T, omega, q) -> csum, csq, 10 slabs per split
+template <typename T>
+static int launch_sweep_opw2_t(temx_plan* pl, const FieldPtrs<5>& fp, double* partial, const Split& sp, hipStream_t st) {
+  const int2* cuts = nullptr;
+  if (int rc = class_cuts(pl, sp.nsplit * 4, &cuts, true)) return rc;
+  dim3 grid(sp.grid), block(256);
+  constexpr int PDv = sizeof(T) == 4 ? TEMX_CLS_OP_PD_F32 : TEMX_CLS_OP_PD;
+#define TEMX_LSW(TBSv)                                                                                       \
+  hipLaunchKernelGGL((sweep_opw_kernel<T, TBSv, PDv, 2>), grid, block, 0, st, fp, pl->D, pl->K, pl->ycls.d(), \
+                     static_cast<const int4*>(pl->crow.p), cuts, pl->colscale.d(), partial, sp.nsplit, sp.ndt, \
+                     pl->csum.d(), pl->csq.d())
+  switch (pl->TBS) {
+    case 2: TEMX_LSW(2); break;
+    case 4: TEMX_LSW(4); break;
+    case 7: TEMX_LSW(7); break;
+    default: TEMX_LSW(8); break;
+  }
+#undef TEMX_LSW
   HIPCHK(hipGetLastError());
   return TEMX_OK;
 }
@@ -1868,12 +1927,15 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
           const size_t need4 = (size_t)std::max(pl->sp_cflux.nsplit * 3, sp_op.nsplit * 7) * pl->K * D * 8;
           if ((rc = pl->partial.ensure(std::max(need4, pl->partial.bytes)))) return rc;
           if ((rc = pl->Pq.ensure((size_t)3 * pl->K * D * 8))) return rc;
+          // TEM + one tracer in one sweep: the four waves of a workgroup share a d-tile (one workgroup per CU)
+          pl->sp_copw = choose_split(D, std::max<int64_t>(1, cunits / 4), pl->num_cu, 1, 8);
         }
       }
     }
     // work cuts now, not at the first launch: launches must stay legal inside a stream capture
     const int2* cuts_unused = nullptr;
     if (pl->onepass && (rc = class_cuts(pl, pl->sp_cproj4.nsplit, &cuts_unused, true))) return rc;
+    if (pl->onepass && (rc = class_cuts(pl, pl->sp_copw.nsplit * 4, &cuts_unused, true))) return rc;
     for (int nsub : {pl->sp_cproj4.nsplit, pl->sp_cproj1.nsplit, pl->sp_ceddy.nsplit * (8 / edpw)})
       if ((rc = class_cuts(pl, nsub, &cuts_unused))) return rc;
   }
@@ -2275,6 +2337,63 @@ int temx_tracer_stage2_from_sums(temx_plan* pl, const double* Bq, double* Bq2, v
   // Bq2 = (projected co-moments of q v, q omega from the sweep) + (projected n (m_q - qb)(m_v - vb) terms)
   return launch_reduce(pl, pl->partial.d(), pl->sp_cflux.nsplit, (int64_t)2 * pl->K * pl->D, Bq2, st, -1,
                        pl->Pq2.d());
+}
+
+// TEM stage 1 and the tracer's one-pass stage 1 in ONE sweep over (u, v, T, omega, q): the fields are read once
+// for both (40 B per grid point instead of 32 + 24).  State afterwards: as after temx_tem_stage1 followed by
+// temx_tracer_stage1_sums.
+int temx_tem_tracer_stage1(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap,
+                           const void* q, int dtype, double* B4, double* Bq, void* stream) {
+  int rc = tem_ready(pl);
+  if (rc) return rc;
+  if (!ua || !va || !ta || !wap || !q || !B4 || !Bq) return fail(TEMX_EINVAL, "null argument");
+  if (dtype != TEMX_F64 && dtype != TEMX_F32) return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
+  if (!(pl->cls && pl->onepass) || pl->large)
+    return fail(TEMX_ESTATE, "the fused TEM + tracer sweep needs the one-pass class path (temx_plan_one_pass)");
+  HIPCHK(hipSetDevice(pl->device));
+  if ((rc = tracer_ws(pl))) return rc;
+  hipStream_t st = S_(stream);
+  const Split& sp = pl->sp_copw;
+  const int64_t KD = (int64_t)pl->K * pl->D;
+  if ((rc = pl->csq.ensure((size_t)pl->cgroups * sp.ndt * 2 * 64 * 8))) return rc;
+  if ((rc = pl->Pq2.ensure((size_t)2 * KD * 8))) return rc;
+  if ((rc = pl->partial.ensure(std::max((size_t)sp.nsplit * 10 * KD * 8, pl->partial.bytes)))) return rc;
+  pl->op_valid = pl->c4_valid = pl->tq_valid = false;
+  FieldPtrs<5> fp;
+  fp.p[0] = ua; fp.p[1] = va; fp.p[2] = ta; fp.p[3] = wap; fp.p[4] = q;
+  TimedLaunch tl{};
+  time_begin(pl, 0, st, tl);
+  rc = dtype == TEMX_F64 ? launch_sweep_opw2_t<double>(pl, fp, pl->partial.d(), sp, st)
+                         : launch_sweep_opw2_t<float>(pl, fp, pl->partial.d(), sp, st);
+  time_end(pl, 0, st, tl);
+  if (rc) return rc;
+  // 10 slabs per split: u v theta omega | q | u v, u omega, v theta | q v, q omega
+  const double* P = pl->partial.d();
+  if ((rc = launch_reduce(pl, P, sp.nsplit, 4 * KD, B4, st, 10 * KD))) return rc;
+  if ((rc = launch_reduce(pl, P + 4 * KD, sp.nsplit, KD, Bq, st, 10 * KD))) return rc;
+  if ((rc = launch_reduce(pl, P + 5 * KD, sp.nsplit, 3 * KD, pl->Pq.d(), st, 10 * KD))) return rc;
+  if ((rc = launch_reduce(pl, P + 8 * KD, sp.nsplit, 2 * KD, pl->Pq2.d(), st, 10 * KD))) return rc;
+  pl->op_valid = true;
+  pl->tq_valid = true;
+  return TEMX_OK;
+}
+
+int temx_tem_tracer_run(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap,
+                        const void* q, int dtype, double* results, double* zonal, double* tres, double* tzon,
+                        void* stream) {
+  int rc = tem_ready(pl);
+  if (rc) return rc;
+  if (!q || !tres) return fail(TEMX_EINVAL, "null argument");
+  if (!(pl->cls && pl->onepass) || pl->large) {      // any other path: the two runs one after the other
+    if ((rc = temx_tem_run(pl, ua, va, ta, wap, dtype, results, zonal, stream))) return rc;
+    return temx_tracer_run(pl, q, va, wap, dtype, tres, tzon, stream);
+  }
+  if ((rc = tracer_ws(pl))) return rc;
+  if ((rc = temx_tem_tracer_stage1(pl, ua, va, ta, wap, q, dtype, pl->B4.d(), pl->Bq.d(), stream))) return rc;
+  if ((rc = temx_tem_stage2_from_sums(pl, pl->B4.d(), pl->B3.d(), stream))) return rc;
+  if ((rc = temx_tem_stage3(pl, pl->B3.d(), results, zonal, stream))) return rc;
+  if ((rc = temx_tracer_stage2_from_sums(pl, pl->Bq.d(), pl->Bq2.d(), stream))) return rc;
+  return temx_tracer_stage3(pl, pl->Bq2.d(), tres, tzon, stream);
 }
 
 int temx_tracer_run(temx_plan* pl, const void* q, const void* va, const void* wap, int dtype,

@@ -263,6 +263,41 @@ class Plan:
                                        _ptr(tzon) if tzon is not None else None, self._stream()))
         return tres, tzon
 
+    def _alloc_tracer(self, want_zonal):
+        tres = torch.empty((len(_lib.TRACER_RESULT_NAMES), self.M, self.nlev, self.nt), dtype=torch.float64,
+                           device=self.device)
+        tzon = None
+        if want_zonal:
+            tzon = torch.empty((len(_lib.TRACER_ZONAL_NAMES), self.M, self.nlev, self.nt), dtype=torch.float64,
+                               device=self.device)
+        return tres, tzon
+
+    def tem_tracer_run(self, ua, va, ta, wap, q, want_zonal=False):
+        """TEM and one tracer in one call; on the one-pass class path the five arrays are swept ONCE
+        (temx_tem_tracer_run).  Returns (results, zonal, tracer results, tracer zonal)."""
+        (u, v, t, w), dt = self._four(ua, va, ta, wap)
+        qq = self._field(q, self.D)
+        if qq.dtype != u.dtype:
+            raise TypeError("the tracer must have the dtype of the fields")
+        res, zon = self._alloc_results(want_zonal)
+        tres, tzon = self._alloc_tracer(want_zonal)
+        check(self.lib.temx_tem_tracer_run(self._h, _ptr(u), _ptr(v), _ptr(t), _ptr(w), _ptr(qq), dt, _ptr(res),
+                                           _ptr(zon) if zon is not None else None, _ptr(tres),
+                                           _ptr(tzon) if tzon is not None else None, self._stream()))
+        return res, zon, tres, tzon
+
+    def tem_tracer_stage1(self, ua, va, ta, wap, q):
+        """Stage 1 of the TEM run and of the tracer in one sweep (one-pass class path): (B4, Bq)."""
+        (u, v, t, w), dt = self._four(ua, va, ta, wap)
+        qq = self._field(q, self.D)
+        if qq.dtype != u.dtype:
+            raise TypeError("the tracer must have the dtype of the fields")
+        B4 = torch.empty((4, self.K, self.D), dtype=torch.float64, device=self.device)
+        Bq = torch.empty((self.K, self.D), dtype=torch.float64, device=self.device)
+        check(self.lib.temx_tem_tracer_stage1(self._h, _ptr(u), _ptr(v), _ptr(t), _ptr(w), _ptr(qq), dt, _ptr(B4),
+                                              _ptr(Bq), self._stream()))
+        return B4, Bq
+
     def tracer_stage1(self, q):
         qq = self._field(q, self.D)
         Bq = torch.empty((self.K, self.D), dtype=torch.float64, device=self.device)

@@ -69,7 +69,12 @@ class TEMDiagnostics:
         # ---- the whole numeric pipeline: one engine call (tem_diagnostics.py:252-259) ----
         plan = self.ZM._plan
         plan.set_tem(self.NLEV, self.NT, self._p_np, float(self.p0))
-        self._res, self._zon = plan.tem_run(*self._dev_fields, want_zonal=True)
+        # (the first tracer, when there is one, shares the sweep of the fields: temx_tem_tracer_run)
+        fused = None
+        if self.ntrac:
+            self._res, self._zon, *fused = plan.tem_tracer_run(*self._dev_fields, self._dev_q[0], want_zonal=True)
+        else:
+            self._res, self._zon = plan.tem_run(*self._dev_fields, want_zonal=True)
         if plan.status():                                   # sph_zonal_mean.py:219-221
             raise RuntimeError("Variable has nans! Spectral zonal averager cannot handle nans; "
                                "please replace or remove them")
@@ -80,7 +85,10 @@ class TEMDiagnostics:
         self._tres, self._tzon, self._teddy = [], [], [None] * self.ntrac
         self._last_tracer = None
         for i in range(self.ntrac):
-            tres, tzon = plan.tracer_run(self._dev_q[i], self._dev_fields[1], self._dev_fields[3], want_zonal=True)
+            if i == 0 and fused is not None:
+                tres, tzon = fused
+            else:
+                tres, tzon = plan.tracer_run(self._dev_q[i], self._dev_fields[1], self._dev_fields[3], want_zonal=True)
             self._tres.append(tres)
             self._tzon.append(tzon)
             self._last_tracer = i

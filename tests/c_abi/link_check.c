@@ -13,7 +13,7 @@ int main(void) {
       (const void*)temx_tem_stage2, (const void*)temx_tem_stage2_from_sums, (const void*)temx_tem_stage3, (const void*)temx_tem_run,
       (const void*)temx_tem_eddy, (const void*)temx_tem_eddy_rows, (const void*)temx_tracer_stage1, (const void*)temx_tracer_stage2,
       (const void*)temx_tracer_stage3, (const void*)temx_tracer_stage1_sums, (const void*)temx_tracer_stage2_from_sums,
-      (const void*)temx_tracer_run, (const void*)temx_tracer_eddy,
+      (const void*)temx_tracer_run, (const void*)temx_tem_tracer_stage1, (const void*)temx_tem_tracer_run, (const void*)temx_tracer_eddy,
       (const void*)temx_status, (const void*)temx_synth_fields, (const void*)temx_mfma_f64_peak,
       (const void*)temx_kernel_timing, (const void*)temx_kernel_timing_read};
   unsigned n = (unsigned)(sizeof(syms) / sizeof(syms[0])), i, ok = 0;

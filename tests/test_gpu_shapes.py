@@ -616,3 +616,59 @@ def test_one_pass_tracer_reads_the_fields_once(force_one_pass, monkeypatch):
         assert e <= 1e-10, (n, e)
     assert not plan.status()
     plan.close()
+
+
+@pytest.mark.parametrize("ne,nlev,nt,dtype,L", [
+    (8, 16, 4, np.float64, 50),      # D = 64: exact d-tiles
+    (8, 13, 3, np.float64, 50),      # D = 39: ragged last d-tile, work cuts with unequal group counts
+    (12, 20, 3, np.float32, 50),     # fp32 inputs
+    (8, 16, 5, np.float64, 12),      # TBS = 2
+])
+def test_tem_and_tracer_in_one_sweep(force_one_pass, ne, nlev, nt, dtype, L):
+    """TEMDiagnostics(q=...) knows its tracer up front (tem_diagnostics.py:241-259, 532-538,
+    560-570), so temx_tem_tracer_run reads (u, v, T, omega, q) ONCE (four waves share a d-tile, ten
+    projections).  Against the oracle, against the separate TEM and tracer runs, in staged form, and the
+    state contract."""
+    from oracle import tem_oracle as orc
+    from pytemdiags_amd import _lib, engine, synth
+    lat, lon = synth.cubed_sphere_gll(ne)
+    plev = synth.pressure_levels(nlev)
+    f = synth.analytic_fields(lat, lon, plev, nt, seed=31, dtype=dtype)
+    q = synth.analytic_tracer(lat, lon, plev, nt).astype(dtype)
+    ref = orc.TEMOracle(*f, lat, plev, L=L, mode="factorised", q=[q])
+    plan = engine.Plan(lat, ref.lat, L)
+    plan.set_tem(nlev, nt, plev * 100)
+    d = [torch.as_tensor(x, device="cuda:0") for x in f]
+    dq = torch.as_tensor(q, device="cuda:0")
+    tol = 1e-10 if dtype == np.float64 else 2e-5
+    res, zon, tres, tzon = plan.tem_tracer_run(*d, dq, want_zonal=True)
+    assert not plan.status()
+    for i, n in enumerate(_lib.RESULT_NAMES):
+        assert fieldnorm_err(res[i].cpu().numpy(), getattr(ref, n)()) <= tol, n
+    for i, n in enumerate(_lib.ZONAL_NAMES):
+        assert fieldnorm_err(zon[i].cpu().numpy(), getattr(ref, n)) <= tol, n
+    for k, n in enumerate(_lib.TRACER_RESULT_NAMES):
+        assert fieldnorm_err(tres[k].cpu().numpy(), getattr(ref, n)(0)) <= tol, n
+    for k, n in enumerate(_lib.TRACER_ZONAL_NAMES):
+        assert fieldnorm_err(tzon[k].cpu().numpy(), getattr(ref, n)[0]) <= tol, n
+    # the separate runs (TEM sweep, then the tracer's own stages) agree to rounding
+    r2, _ = plan.tem_run(*d)
+    t2, _ = plan.tracer_run(dq, d[1], d[3])
+    for a, b in ((res, r2), (tres, t2)):
+        for i in range(a.shape[0]):
+            assert float((a[i] - b[i]).abs().max()) <= (1e-11 if dtype == np.float64 else 1e-5) * float(b[i].abs().max()), i
+    if plan.one_pass:
+        # staged form == fused form bit for bit; B4 / Bq are what an ncol-sharded caller all-reduces
+        B4, Bq = plan.tem_tracer_stage1(*d, dq)
+        B4b = plan.tem_stage1(*d)
+        assert float((B4 - B4b).abs().max()) <= 1e-12 * float(B4b.abs().max())
+        with pytest.raises(_lib.TemxError):             # stage 1 on its own voids the tracer's class sums
+            plan.tracer_stage2_from_sums(Bq)
+        B4, Bq = plan.tem_tracer_stage1(*d, dq)
+        with pytest.raises(_lib.TemxError):             # no TEM stage 2 yet: v, omega coefficients of older fields
+            plan.tracer_stage2_from_sums(Bq)
+        r3, _ = plan.tem_stage3(plan.tem_stage2_from_sums(B4))
+        t3, _ = plan.tracer_stage3(plan.tracer_stage2_from_sums(Bq))
+        assert torch.equal(r3, res) and torch.equal(t3, tres)
+    assert not plan.status()
+    plan.close()

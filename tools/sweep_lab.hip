@@ -182,6 +182,22 @@ int run(int64_t N, int64_t D, int reps, const char* only) {
   std::mt19937 gen(7);
   std::shuffle(perm.begin(), perm.end(), gen);
   std::vector<HCls> cls;
+  if (const char* cf = getenv("LAB_CLASSES")) {     // int32 file: ncls, then per class nN, nS, rows (tools/dump_classes.py)
+    FILE* fh = fopen(cf, "rb");
+    if (!fh) { printf("cannot open %s\n", cf); return 1; }
+    int32_t nc = 0;
+    if (fread(&nc, 4, 1, fh) != 1) return 1;
+    for (int i = 0; i < nc; ++i) {
+      int32_t hdr[2];
+      if (fread(hdr, 4, 2, fh) != 2) return 1;
+      HCls c; c.n.resize(hdr[0]); c.s.resize(hdr[1]);
+      if (hdr[0] && fread(c.n.data(), 4, hdr[0], fh) != (size_t)hdr[0]) return 1;
+      if (hdr[1] && fread(c.s.data(), 4, hdr[1], fh) != (size_t)hdr[1]) return 1;
+      cls.push_back(c);
+    }
+    fclose(fh);
+    printf("classes from %s: %zu\n", cf, cls.size());
+  } else
   for (int64_t i = 0; i < N; i += 16) {
     HCls c;
     const int64_t m = std::min<int64_t>(16, N - i);
@@ -241,14 +257,40 @@ int run(int64_t N, int64_t D, int reps, const char* only) {
   }
   auto add_w = [&](auto pdc) {
     constexpr int PD = decltype(pdc)::value;
-    Split sp = choose_split(D, cunits / 4, 512, 1, 8);
+    Split sp = choose_split(D, cunits / 4, 256 * TEMX_OPW_WPS, 1, 8);
     int2* cuts = reinterpret_cast<int2*>(to_dev(group_cuts(gb0, sp.nsplit * 4)));
-    vars.push_back({"opw   8B loads, shared d-tile, 2 waves/SIMD, PD=" + std::to_string(PD), sp.nsplit, [=](double* cs_out) {
+    vars.push_back({"opw   8B loads, shared d-tile, " + std::to_string(TEMX_OPW_WPS) + " waves/SIMD, PD=" + std::to_string(PD), sp.nsplit, [=](double* cs_out) {
       hipLaunchKernelGGL((sweep_opw_kernel<T, TBS, PD, 0>), dim3(sp.grid), dim3(256), 0, 0, fp, D, K, d_ycls,
-                         reinterpret_cast<const int4*>(d_crow), cuts, d_cs, partial, sp.nsplit, sp.ndt, cs_out); }});
+                         reinterpret_cast<const int4*>(d_crow), cuts, d_cs, partial, sp.nsplit, sp.ndt, cs_out, (double*)nullptr); }});
   };
   add_w(std::integral_constant<int, sizeof(T) == 8 ? 2 : 4>{});
   add_w(std::integral_constant<int, sizeof(T) == 8 ? 3 : 6>{});
+#ifdef LAB_FUSED
+  // TEM + one tracer in one sweep: five fields, ten projections (its outputs are not compared here: the
+  // library's tests do that; slabs differ from the reference kernel's seven)
+  static T* qf = nullptr;
+  if (!qf) {
+    CHK(hipMalloc(&qf, (size_t)N * D * sizeof(T)));
+    hipLaunchKernelGGL(fill_kernel<T>, dim3(4096), dim3(256), 0, 0, qf, N * D, 99u, 1e-3, 1e-3);
+    CHK(hipDeviceSynchronize());
+  }
+  static double* csq = nullptr;
+  if (!csq) CHK(hipMalloc(&csq, csum_n * 8 / 4));
+  auto add_f = [&](auto pdc) {
+    constexpr int PD = decltype(pdc)::value;
+    Split sp = choose_split(D, cunits / 4, getenv("LAB_SLOTS") ? atoi(getenv("LAB_SLOTS")) : 256, 1, 8);
+    int2* cuts = reinterpret_cast<int2*>(to_dev(group_cuts(gb0, sp.nsplit * 4)));
+    FieldPtrs<5> f5;
+    for (int i = 0; i < 4; ++i) f5.p[i] = fp.p[i];
+    f5.p[4] = qf;
+    double* csq_ = csq;
+    vars.push_back({"opw2  TEM + tracer, 5 fields, shared d-tile, 1 wave/SIMD, PD=" + std::to_string(PD) + " [53.7 GB counted, 67.2 read]", sp.nsplit * 10 / 7 + 1, [=](double* cs_out) {
+      hipLaunchKernelGGL((sweep_opw_kernel<T, TBS, PD, 2>), dim3(sp.grid), dim3(256), 0, 0, f5, D, K, d_ycls,
+                         reinterpret_cast<const int4*>(d_crow), cuts, d_cs, partial, sp.nsplit, sp.ndt, cs_out, csq_); }});
+  };
+  add_f(std::integral_constant<int, sizeof(T) == 8 ? 2 : 4>{});
+  add_f(std::integral_constant<int, sizeof(T) == 8 ? 3 : 6>{});
+#endif
   {   // parity pair with redundant loads: 2 d-tiles per workgroup
     Split sp = choose_split(D, cunits, 512, 2, 8);
     int2* cuts = reinterpret_cast<int2*>(to_dev(group_cuts(gb0, sp.nsplit)));

@@ -33,3 +33,25 @@ for form in ("one", "two"):
     print("ne%dx%dx%d tracer_run %s (plan.one_pass=%s): %.3f ms -> %.3g grid-points/s, %.2f TB/s of the 3 fields"
           % (ne, nlev, nt, form, plan.one_pass, ms, pts / ms * 1e3, 3 * 8 * pts / ms / 1e9), flush=True)
     plan.close()
+
+# TEM + one tracer: the two runs one after the other against the fused sweep (temx_tem_tracer_run)
+os.environ.pop("TEMX_TWO_PASS", None)
+plan = engine.Plan(lat, lat_zm, 50)
+plan.set_tem(nlev, nt, plev * 100)
+def timeit(fn, reps=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+sep = timeit(lambda: (plan.tem_run(*f), plan.tracer_run(q, f[1], f[3])))
+plan.kernel_timing(True)
+fus = timeit(lambda: plan.tem_tracer_run(*f, q))
+sw, n = plan.kernel_timing_read(0)
+print("ne%dx%dx%d TEM + one tracer: separate runs %.3f ms, one fused sweep %.3f ms (its sweep %.3f ms = %.2f TB/s of the 5 "
+      "fields); one_pass=%s" % (ne, nlev, nt, sep, fus, sw or float("nan"), 5 * 8 * lat.size * nlev * nt / (sw or 1) / 1e9, plan.one_pass), flush=True)
+plan.close()
