@@ -7,9 +7,11 @@
 // The class sums are accumulated about the side's first member (S~ = sum (x - x0), q~ = sum
 // (u - u0)(v - v0)) and converted when the side is complete:  S = S~ + n x0,  C_uv = q~ - S~_u S~_v / n.
 //
-// This is the dominant kernel of the pipeline and an HBM stream, but with one wave per SIMD (98 fp64
-// accumulators) every VALU instruction sits on the critical path next to the loads, so the loop body is
-// kept lean:
+// This is the dominant kernel of the pipeline and an HBM stream.  Round 3 (tools/sweep_lab.hip):
+// built without its class-sum stores it reads at 5.98 TB/s -- the chip's streaming ceiling -- and forms with
+// two waves per SIMD or 16-byte loads (kernels_op2.hpp) are no faster with the stores in place: the 12.5 % of
+// store traffic costs 2.2 of the 11.1 ms, and that is a property of the memory system (an independent writer
+// kernel costs the same).  One wave per SIMD (98 fp64 accumulators); the loop body is kept lean:
 //   * D is passed as 32 bits, so the element offset of a member row is one v_mad_u64_u32;
 //   * the sums of the side being walked live in ONE set of registers (no per-batch north / south
 //     selects); they move to the "north" set when the southern batches of the group begin;

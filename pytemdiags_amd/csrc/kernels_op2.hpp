@@ -1,17 +1,21 @@
-// kernels_op2.hpp -- sweep 1 of the one-pass latitude-class path, forms that hold two waves per SIMD
-// and / or read the member rows with wider loads (the algebra and the outputs are those of
-// sweep_op_kernel in kernels_op.hpp: csum records + partial[split][NA][K][D]).
+// kernels_op2.hpp -- other forms of sweep 1 of the one-pass latitude-class path (the algebra and the outputs are
+// those of sweep_op_kernel in kernels_op.hpp: class-sum records + partial[split][NA][K][D]).
 //
-// What limits sweep_op_kernel is its register budget: 98 fp64 accumulators (7 projections x 14 harmonic
-// blocks of one d-tile) leave room for ONE wave per SIMD.  Two independent remedies:
+// Round 2 took the 98 fp64 accumulators of sweep_op_kernel (7 projections x 14 harmonic blocks of one d-tile,
+// one wave per SIMD) for what holds it at 4.5-4.8 TB/s.  The forms below remove that limit in two independent
+// ways -- and measured the same 11.9 ms on ne120 x 72 x 30 (tools/sweep_lab.hip): built without
+// the class-sum stores every form, the one-wave kernel included, reads at 6.0-6.26 TB/s.  The store stream
+// binds the sweep, not the occupancy.  What stays in the library from this file is the shared-d-tile form in
+// its five-field instantiation (KIND = 2: TEM + one tracer in one sweep, ten projections -- more accumulators
+// than one wave can hold); the others are kept for the lab.
 //
-//  * shared d-tile (WS = 4, sweep_opw_kernel and sweep_op16_kernel<.., 4>): the four waves of a workgroup
+//  * shared d-tile (sweep_opw_kernel, and sweep_op16_kernel<.., WS = 4>): the four waves of a workgroup
 //    work on ONE d-tile.  Each wave walks its own run of class-groups (its own member rows: nothing is
 //    read twice) and forms that group's sums; at the end of every class-group the four waves exchange the
-//    7 sums + 7 differences per lane and the group's Y blocks through LDS (double buffered, ONE workgroup
+//    NA sums + NA differences per lane and the group's Y blocks through LDS (double buffered, ONE workgroup
 //    barrier per round; the barrier does not wait for the global loads in flight), and every wave
 //    projects all four groups of the round onto ITS quarter of the harmonic blocks: 28 accumulators per
-//    wave instead of 98, two workgroups per CU.
+//    wave instead of 98, two workgroups per CU (KIND = 2: 40 accumulators, one workgroup per CU).
 //
 //  * row pairs (sweep_op16_kernel): a lane owns two adjacent columns of a member row and the two halves
 //    of a 16-lane group own the northern and the southern side of a class: lane = 16 k + 8 h + cp (class
@@ -20,7 +24,10 @@
 //    cross-lane traffic is one swap with lane ^ 8 per finished sum (DPP), after which lane (k, h, cp)
 //    holds the {north, south} pair of column 2 cp + h -- the MFMA operand layout with the columns of the
 //    d-tile permuted (a permutation of the 16 independent columns of the product).
-//    Row table: crow16[batch][8 lane groups][MBV], same entry format as crow.
+//    Row table: crow16[batch][8 lane groups][MBV], same entry format as crow (built by the lab only).
+//
+//  * parity pair with redundant loads (sweep_opp_kernel, VERDICT r02's option (a)): 48.8 ms.  Loads served
+//    by L1 / L2 instead of HBM are far from free at this rate.
 #pragma once
 #include "kernels_op.hpp"
 
