@@ -791,4 +791,409 @@ sweep_opp_kernel(FieldPtrs<4> fp, int64_t D, int K, const double* __restrict__ y
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// sweep_os_kernel -- ONE sweep, no class-sum stream: the eddy-product sums follow afterwards from
+//   F_l = P_l - sum_m beta_m M^a_lm - sum_m alpha_m M^b_lm + alpha^T T_l beta,   M^a_lm = sum_k g(l,m,k) A_k
+// (Legendre product linearisation), which needs the projections A_k of the four fields up to degree 2L and
+// the projections P_l of the three products up to degree L -- all of fields from which a band-limited
+// REFERENCE r = sum_m rho_m Y_m (coefficients rho from a subsample pre-pass) has been subtracted, so that
+// no term is a difference of large numbers.  Per class side (sums about the first member x0 as in
+// sweep_op_kernel, n members, S~ = sum (x - x0), q~ = sum (a - a0)(b - b0)):
+//     S'  = S~ + n (x0 - r)                      sum of the shifted field
+//     P'  = q~ - S~_a S~_b / n + n (m_a - r_a)(m_b - r_b),   m - r = S~ / n + x0 - r
+// with r reconstructed at the class latitudes per class-group (4 x 2 NBR MFMAs, operands rho in LDS).
+// Same row table and work cuts as sweep_op_kernel; one wave = one d-tile, one wave per SIMD.
+//   ycx[group][2 TBX][16]   basis blocks up to degree 2L (TBX even blocks, then TBX odd ones)
+//   rho[4][4 * 2 NBR ...]   reference coefficients, rows harm(tb, g) as C in flux_cls_kernel: rho[f][K4][D]
+//   px[split][4][KX][D]     field projections (KX = 2L + 1),   pp[split][3][K][D]  product projections
+// ------------------------------------------------------------------------------------------------
+template <int TBX>
+__device__ __forceinline__ constexpr int symx_harm(int tb, int i) {
+  return tb < TBX ? 2 * (4 * tb + i) : 2 * (4 * (tb - TBX) + i) + 1;
+}
+
+template <typename T, int TBS, int TBX, int NBR, int PD>
+__global__ void __launch_bounds__(256, 1)
+sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restrict__ ycx,
+                const int4* __restrict__ crow, const int2* __restrict__ csplit,
+                const double* __restrict__ colscale, const double* __restrict__ rho, int K4,
+                double* __restrict__ px, double* __restrict__ pp, int nsplit, int ndt) {
+  constexpr int NBX = 2 * TBX;                // blocks of the extended basis
+  constexpr int YE = NBX * 16;
+  constexpr int YJ = (YE + 63) / 64;
+  constexpr int MB = CLS_MB;
+  static_assert(NBR <= TBS && TBS <= TBX, "reference degree <= L <= 2L");
+  // the 3 x 2 TBS product accumulators live in wave-private LDS (146 accumulators do not fit the register file
+  // next to the load ring): read-modify-write once per class-group
+  extern __shared__ double lds[];             // [4 waves][YE] Y blocks, [4 waves][4][2 NBR][64] reference operands, [4 waves][3][2 TBS][64] product accumulators
+  int split, dq;
+  if (!wg_work((ndt + 3) / 4, nsplit, split, dq)) return;
+  const int wave = uniform_wave(), lane = threadIdx.x & 63;
+  const int c = lane & 15, g = lane >> 4;
+  const int dt = dq * 4 + wave;
+  if (dt >= ndt) return;
+  const int64_t d = (int64_t)dt * 16 + c;
+  const bool dvalid = d < D;
+  const int64_t dcl = dvalid ? d : D - 1;
+  const int b0 = __builtin_amdgcn_readfirstlane(csplit[split].x);
+  const int b1 = __builtin_amdgcn_readfirstlane(csplit[split + 1].x);
+  int grp = __builtin_amdgcn_readfirstlane(csplit[split].y);
+  const uint32_t aoff_p = (uint32_t)(g * 4 + (lane & 3));
+  const uint32_t aoff_r = (uint32_t)((lane & 3) * 4 + g);
+  double* yst = lds + wave * YE;
+  double* cb = lds + 4 * YE + wave * (4 * 2 * NBR * 64) + lane;
+  double* apl = lds + 4 * YE + 4 * (4 * 2 * NBR * 64) + wave * (3 * 2 * TBS * 64) + lane;
+  const double sth = colscale != nullptr ? colscale[dcl] : 1.0;
+#pragma unroll
+  for (int i = 0; i < 3 * 2 * TBS; ++i) apl[i * 64] = 0.0;
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int tb = 0; tb < 2 * NBR; ++tb) {   // (reference blocks: the first NBR even and the first NBR odd blocks)
+      const int l = tb < NBR ? 2 * (4 * tb + g) : 2 * (4 * (tb - NBR) + g) + 1;
+      const double v = rho[((int64_t)f * K4 + (l < K ? l : K - 1)) * D + dcl];
+      cb[(f * 2 * NBR + tb) * 64] = l < K ? v : 0.0;
+    }
+  const T* fb[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) fb[f] = reinterpret_cast<const T*>(fp.p[f]) + dcl;
+
+  double ax[4][NBX];
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int t = 0; t < NBX; ++t) ax[f][t] = 0.0;
+  using KD = OpKind<0>;
+  double s[4], q[3], x0[4], cnt = 0.0;
+  double sN[4], qN[3], x0N[4], cntN = 0.0;      // the finished northern side, still about its own origin
+#pragma unroll
+  for (int f = 0; f < 4; ++f) s[f] = x0[f] = sN[f] = x0N[f] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) q[k] = qN[k] = 0.0;
+  bool north_open = false, prev_south = false;
+  const uint32_t D32 = (uint32_t)D;
+
+  T xb[PD][MB][4];
+  int er[PD][MB];
+  double ys[YJ];
+  auto load_ys = [&](int gi) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < YJ; ++j) ys[j] = (ycx + (int64_t)gi * YE)[(lane + 64 * j) < YE ? (lane + 64 * j) : 0];
+  };
+  auto issue = [&](auto pc, const int4 rv) __attribute__((always_inline)) {
+    constexpr int P = decltype(pc)::value;
+    er[P][0] = rv.x; er[P][1] = rv.y; er[P][2] = rv.z; er[P][3] = rv.w;
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+      const uint64_t off = (uint64_t)(uint32_t)(er[P][j] & CLS_ROWMASK) * D32;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) xb[P][j][f] = TEMX_XLOAD(fb[f] + off);
+    }
+  };
+  auto park_north = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { sN[f] = s[f]; x0N[f] = x0[f]; s[f] = 0.0; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { qN[k] = q[k]; q[k] = 0.0; }
+    cntN = cnt;
+    cnt = 0.0;
+  };
+  int4 rn;
+  auto step = [&](auto pc, int b) __attribute__((always_inline)) {
+    constexpr int P = decltype(pc)::value;
+    if (b + (PD - 1) < b1) {
+      const int4 r1 = rn;
+      rn = crow[(int64_t)(b + PD) * 4 + g];
+      issue(std::integral_constant<int, (P + PD - 1) % PD>{}, r1);
+    }
+    const int fl = __builtin_amdgcn_readfirstlane(er[P][0]) >> 27;
+    const bool south = (fl & (CLS_SOUTH << 1)) != 0;
+    if ((fl & (CLS_FIRST << 1)) || (south && !prev_south)) {
+      if (south && north_open) park_north();
+      north_open = !south;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) x0[f] = (double)xb[P][0][f];
+    }
+    prev_south = south;
+    if (fl & 1) {
+#pragma unroll
+      for (int j = 0; j < MB; ++j) {
+        const double w = er[P][j] < 0 ? 0.0 : 1.0;
+        double dx[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) dx[f] = (double)xb[P][j][f] - x0[f];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) s[f] += w * dx[f];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) q[k] += (w * dx[KD::pa(k)]) * dx[KD::pb(k)];
+        cnt += w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < MB; ++j) {
+        double dx[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) dx[f] = (double)xb[P][j][f] - x0[f];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) s[f] += dx[f];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) q[k] += dx[KD::pa(k)] * dx[KD::pb(k)];
+      }
+      cnt += (double)MB;
+    }
+    if (fl & (CLS_LAST << 1)) {
+      prev_south = false;
+#pragma unroll
+      for (int j = 0; j < YJ; ++j)
+        if (lane + 64 * j < YE) yst[lane + 64 * j] = ys[j];
+      if (north_open) park_north();             // the group has no southern batch: the open side is the northern one
+      north_open = false;
+      ++grp;
+      load_ys(grp);
+      // ---- reference at the class latitudes: E = even part, O = odd part; r_N = E + O, r_S = E - O
+      double E[4], O[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) E[f] = O[f] = 0.0;
+#pragma unroll
+      for (int tb = 0; tb < 2 * NBR; ++tb) {
+        const int blk = tb < NBR ? tb : TBX + (tb - NBR);
+        const double ya = yst[blk * 16 + aoff_r];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          if (tb < NBR)
+            E[f] = TEMX_MFMA4(ya, cb[(f * 2 * NBR + tb) * 64], E[f]);
+          else
+            O[f] = TEMX_MFMA4(ya, cb[(f * 2 * NBR + tb) * 64], O[f]);
+        }
+      }
+      // ---- sums of the shifted fields and of their products, per side (theta = T x the column scale)
+      double SN[4], SS[4], PN[3], PS[3], mN[4], mS[4];
+      const double rnN = cntN > 0.0 ? 1.0 / cntN : 0.0, rnS = cnt > 0.0 ? 1.0 / cnt : 0.0;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const double sc = f == 2 ? sth : 1.0;
+        mN[f] = (sN[f] * rnN + x0N[f]) * sc - (E[f] + O[f]);     // side mean minus the reference
+        mS[f] = (s[f] * rnS + x0[f]) * sc - (E[f] - O[f]);
+        SN[f] = cntN * mN[f];
+        SS[f] = cnt * mS[f];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double sc = k == 2 ? sth : 1.0;
+        PN[k] = (qN[k] - sN[KD::pa(k)] * sN[KD::pb(k)] * rnN) * sc + cntN * mN[KD::pa(k)] * mN[KD::pb(k)];
+        PS[k] = (q[k] - s[KD::pa(k)] * s[KD::pb(k)] * rnS) * sc + cnt * mS[KD::pa(k)] * mS[KD::pb(k)];
+      }
+#pragma unroll
+      for (int t = 0; t < NBX; ++t) {
+        const double ya = yst[t * 16 + aoff_p];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) ax[f][t] = TEMX_MFMA4(ya, t < TBX ? SN[f] + SS[f] : SN[f] - SS[f], ax[f][t]);
+        const int tp = t < TBX ? t : t - TBX;                     // the product blocks are the first TBS of each parity
+        if (tp < TBS) {
+          const int ta = t < TBX ? tp : TBS + tp;
+          double v[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) v[k] = apl[(k * 2 * TBS + ta) * 64];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) v[k] = TEMX_MFMA4(ya, t < TBX ? PN[k] + PS[k] : PN[k] - PS[k], v[k]);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) apl[(k * 2 * TBS + ta) * 64] = v[k];
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < 4; ++f) s[f] = sN[f] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) q[k] = qN[k] = 0.0;
+      cnt = cntN = 0.0;
+    }
+  };
+
+  if (b0 < b1) {
+    load_ys(grp);
+    rn = crow[(int64_t)b0 * 4 + g];
+    static_for<PD - 1>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int k = decltype(kc)::value;
+      const int4 r0 = rn;
+      rn = crow[(int64_t)(b0 + k + 1) * 4 + g];
+      if (k == 0 || b0 + k < b1) issue(kc, r0);
+    });
+    for (int b = b0; b < b1; b += PD)
+      static_for<PD>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        if (k == 0 || b + k < b1) step(kc, b + k);
+      });
+  }
+  if (dvalid) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int t = 0; t < NBX; ++t) {
+        const int l = symx_harm<TBX>(t, g);
+        if (l < KX) px[(((int64_t)split * 4 + f) * KX + l) * D + d] = ax[f][t];
+      }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int t = 0; t < 2 * TBS; ++t) {
+        const int l = sym_harm<TBS>(t, g);
+        if (l < K) pp[(((int64_t)split * 3 + k) * K + l) * D + d] = apl[(k * 2 * TBS + t) * 64];
+      }
+  }
+}
+
+// reference coefficients of the single-sweep form: rho[f][l][d] = sum_m Gsinv[l][m] As[f][m][d], l, m < KR
+// (As: projections of a subsample of class-groups onto the first KR harmonics, rows of a [4][KX][D] array)
+__global__ void os_ref_solve_kernel(const double* __restrict__ As, int KX, int KR, int64_t D,
+                                    const double* __restrict__ Gsinv, double* __restrict__ rho) {
+  const int64_t d = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int f = blockIdx.y;
+  if (d >= D) return;
+  double a[16];
+  for (int m = 0; m < KR; ++m) a[m] = As[((int64_t)f * KX + m) * D + d];
+  for (int l = 0; l < KR; ++l) {
+    double v = 0.0;
+    for (int m = 0; m < KR; ++m) v += Gsinv[l * KR + m] * a[m];
+    rho[((int64_t)f * KR + l) * D + d] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// os_contract_kernel: from the projections of the single sweep to the raw sums the rest of the pipeline
+// takes.  Per column d, in the Y basis (A^f_k, k < KX: shifted fields; P^p_l, l < K: shifted products; rho: the
+// reference that was subtracted), with x_q, w_q the Gauss-Legendre nodes and weights (NQ = 2L + 2: exact
+// for degree 4L) and Yq[q][k] = Y_k(x_q):
+//   alpha^f = T (G2inv (T^T A^f[:K]))                    coefficients of the zonal mean of the shifted field
+//   B4^f    = T^T (A^f[:K] + G[:, :KR] rho^f)             raw sums of the ORIGINAL field, plan basis
+//   At^f_q  = sum_k Yq[q][k] A^f_k,   ab^f_q = sum_l Yq[q][l] alpha^f_l      (synthesis at the nodes)
+//   sum_i Y_l abar b   = sum_q 2 pi w_q Y_l(x_q) ab^a_q At^b_q               (Y_l abar is a polynomial of degree <= 2L,
+//                                                                            so only the degree-2L projection of b matters)
+//   c_k  = sum_q 2 pi w_q Yq[q][k] ab^a_q ab^b_q          the product of the two zonal means, degree <= 2L
+//   F_l  = P_l - sum_q 2 pi w_q Yq[q][l] (ab^b_q At^a_q + ab^a_q At^b_q) + sum_k Gx_lk c_k
+//   B3^p = T^T F                                          raw sums of the eddy products, plan basis
+// (the transform form of the Legendre product linearisation: 1.3e5 multiply-adds per column instead of the
+// 1.6e6 of the explicit g(l,m,k) sums).  One workgroup = OSC columns; thread = (row slot, column); every
+// matrix operand is staged in LDS before it is used.
+// ------------------------------------------------------------------------------------------------
+constexpr int OSC = 4;                          // columns per workgroup
+constexpr int OSR = 256 / OSC;                  // row slots
+
+__device__ __forceinline__ void os_stage(double* dst, const double* __restrict__ src, int n, int tid) {
+  for (int i = tid; i < n; i += 256) dst[i] = src[i];
+}
+
+// LDS doubles of os_contract_kernel
+__host__ __device__ inline size_t os_contract_lds(int K, int KX, int NQ) {
+  const size_t big = (size_t)NQ * KX > (size_t)2 * K * K ? (size_t)NQ * KX : (size_t)2 * K * K;
+  return ((size_t)4 * KX + 8 * K + 8 * NQ + 3 * KX + 3 * K) * OSC + big;
+}
+
+__global__ void __launch_bounds__(256)
+os_contract_kernel(const double* __restrict__ Ax, const double* __restrict__ Pp, const double* __restrict__ rho,
+                   int K, int KX, int KR, int NQ, int64_t D, const double* __restrict__ Tm,
+                   const double* __restrict__ G2inv, const double* __restrict__ G, const double* __restrict__ Gx,
+                   const double* __restrict__ Yq, const double* __restrict__ wq2, double* __restrict__ B4,
+                   double* __restrict__ B3) {
+  extern __shared__ double sm[];
+  const int KK = K * K;
+  double* sA = sm;                              // [4][KX][OSC]   projections of the shifted fields
+  double* sAl = sA + 4 * KX * OSC;              // [4][K][OSC]    scratch / Y-basis sums
+  double* sW = sAl + 4 * K * OSC;               // [4][K][OSC]    alpha (from phase 3 on)
+  double* sAt = sW + 4 * K * OSC;               // [4][NQ][OSC]   At
+  double* sAb = sAt + 4 * NQ * OSC;             // [4][NQ][OSC]   ab
+  double* sC = sAb + 4 * NQ * OSC;              // [3][KX][OSC]   c_k per pair
+  double* sF = sC + 3 * KX * OSC;               // [3][K][OSC]    cross terms, then F
+  double* big = sF + 3 * K * OSC;               // T | G2inv, then Yq, then Gx, then T
+  const int tid = threadIdx.x;
+  const int c = tid % OSC, r = tid / OSC;
+  const int64_t d0 = (int64_t)blockIdx.x * OSC, d = d0 + c;
+  const bool dv = d < D;
+  const int64_t dc = dv ? d : D - 1;
+  for (int i = r; i < 4 * KX; i += OSR) sA[i * OSC + c] = Ax[(int64_t)i * D + dc];
+  os_stage(big, Tm, KK, tid);
+  os_stage(big + KK, G2inv, KK, tid);
+  __syncthreads();
+  const double* sT = big;
+  const double* sG2 = big + KK;
+  for (int i = r; i < 4 * K; i += OSR) {        // y = T^T A[:K]
+    const int f = i / K, j = i % K;
+    double v = 0.0;
+    for (int l = 0; l <= j; ++l) v += sT[l * K + j] * sA[(f * KX + l) * OSC + c];
+    sW[i * OSC + c] = v;
+  }
+  __syncthreads();
+  for (int i = r; i < 4 * K; i += OSR) {        // C' = G2inv y
+    const int f = i / K, j = i % K;
+    double v = 0.0;
+    for (int l = 0; l < K; ++l) v += sG2[j * K + l] * sW[(f * K + l) * OSC + c];
+    sAl[i * OSC + c] = v;
+  }
+  __syncthreads();
+  for (int i = r; i < 4 * K; i += OSR) {        // alpha = T C'
+    const int f = i / K, l = i % K;
+    double v = 0.0;
+    for (int j = l; j < K; ++j) v += sT[l * K + j] * sAl[(f * K + j) * OSC + c];
+    sW[i * OSC + c] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < K * KR; i += 256) big[KK + i] = G[(i / KR) * K + (i % KR)];   // G[:, :KR] over G2inv
+  __syncthreads();
+  for (int i = r; i < 4 * K; i += OSR) {        // Y-basis sums of the original fields
+    const int f = i / K, l = i % K;
+    double v = sA[(f * KX + l) * OSC + c];
+    for (int m = 0; m < KR; ++m) v += big[KK + l * KR + m] * rho[((int64_t)f * KR + m) * D + dc];
+    sAl[i * OSC + c] = v;
+  }
+  __syncthreads();
+  for (int i = r; i < 4 * K; i += OSR) {        // B4 = T^T (.)
+    const int f = i / K, j = i % K;
+    double v = 0.0;
+    for (int l = 0; l <= j; ++l) v += sT[l * K + j] * sAl[(f * K + l) * OSC + c];
+    if (dv) B4[((int64_t)f * K + j) * D + d] = v;
+  }
+  __syncthreads();
+  os_stage(big, Yq, NQ * KX, tid);              // Yq[q][k]
+  __syncthreads();
+  for (int i = r; i < 4 * NQ; i += OSR) {       // synthesis at the nodes
+    const int f = i / NQ, q = i % NQ;
+    const double* yq = big + q * KX;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < KX; ++k) a += yq[k] * sA[(f * KX + k) * OSC + c];
+    for (int l = 0; l < K; ++l) b += yq[l] * sW[(f * K + l) * OSC + c];
+    sAt[i * OSC + c] = a;
+    sAb[i * OSC + c] = b;
+  }
+  __syncthreads();
+  for (int i = r; i < 3 * KX; i += OSR) {       // cross terms (rows l < K) and c_k, per pair
+    const int p = i / KX, k = i % KX;
+    const int fa = p == 2 ? 1 : 0, fb = p == 0 ? 1 : (p == 1 ? 3 : 2);       // (u, v) (u, omega) (v, theta)
+    double x = 0.0, cc = 0.0;
+    for (int q = 0; q < NQ; ++q) {
+      const double yw = big[q * KX + k] * wq2[q];
+      const double aa = sAb[(fa * NQ + q) * OSC + c], bb = sAb[(fb * NQ + q) * OSC + c];
+      cc += yw * aa * bb;
+      if (k < K) x += yw * (bb * sAt[(fa * NQ + q) * OSC + c] + aa * sAt[(fb * NQ + q) * OSC + c]);
+    }
+    sC[i * OSC + c] = cc;
+    if (k < K) sF[(p * K + k) * OSC + c] = x;
+  }
+  __syncthreads();
+  os_stage(big, Gx, K * KX, tid);
+  __syncthreads();
+  for (int i = r; i < 3 * K; i += OSR) {        // F = P - cross + Gx c
+    const int p = i / K, l = i % K;
+    double t3 = 0.0;
+    for (int k = 0; k < KX; ++k) t3 += big[l * KX + k] * sC[(p * KX + k) * OSC + c];
+    sF[i * OSC + c] = Pp[((int64_t)p * K + l) * D + dc] - sF[i * OSC + c] + t3;
+  }
+  __syncthreads();
+  os_stage(big, Tm, KK, tid);
+  __syncthreads();
+  for (int i = r; i < 3 * K; i += OSR) {        // B3 = T^T F
+    const int p = i / K, j = i % K;
+    double v = 0.0;
+    for (int l = 0; l <= j; ++l) v += big[l * K + j] * sF[(p * K + l) * OSC + c];
+    if (dv) B3[((int64_t)p * K + j) * D + d] = v;
+  }
+}
+
 }  // namespace temx

@@ -126,6 +126,16 @@ struct temx_plan {
   DevBuf crow, ycls;
   std::map<int, DevBuf> csplits;       // work cuts per number of pieces
   Split sp_cproj4, sp_cproj1, sp_ceddy, sp_cflux;
+  // single-sweep form (kernels_op2.hpp, sweep_os_kernel): no class-sum stream; see build_os_tables / tem_run_os
+  bool os_built = false, os_on = false;
+  int TBX = 0, KX = 0, KR = 0, NQ = 0;
+  std::vector<double> h_xc, h_cnt;     // host copies of the class latitudes (cos colat) and member counts
+  std::vector<int> h_crow;             // host copy of the row table
+  std::vector<int> sgbatch0;           // subsample of class-groups (reference pre-pass): first batch of each (+ total)
+  int64_t sgroups = 0, sbatches = 0;
+  DevBuf ycx, ycx_s, crow_s, rho, rho0, gaunt /* Yq[NQ][KX] */, wq2, Gx, Gsinv, Ax, Axs, Pp;
+  std::map<int, DevBuf> csplits_s;
+  Split sp_os, sp_os_s;
   Split sp_copw;                 // TEM + tracer in one sweep (sweep_opw_kernel<.., 2>): one d-tile per workgroup
   // one-pass form of the class path: sweep 1 also stores per-class sums of products (csum), the
   // flux kernel replaces sweep 2 (kernels_cls.hpp)
@@ -1283,6 +1293,274 @@ static FieldPtrs<4> four(const void* a, const void* b, const void* c, const void
   return fp;
 }
 
+// ---- single-sweep form ---------------------------------------------------------------------------------
+// The class-sum stream costs sweep 1 2.2 of its 11.1 ms and feeds a 1.8 ms flux kernel.  This
+// form needs neither: ONE sweep projects the four fields up to degree 2L and the three products up to degree
+// L (sweep_os_kernel), and the eddy-product sums follow from the Legendre product linearisation
+// (os_contract_kernel).  A band-limited reference of low degree, fitted to a subsample of class-groups in a
+// short pre-pass with the same kernel, is subtracted first so that no term is a difference of large numbers
+// (tools/proto/single_sweep_numerics.py).  Used by temx_tem_run only (the staged, all-reducible stages keep the
+// class-sum path).
+
+// Gauss-Legendre nodes and weights on [-1, 1] (long double, Newton on P_n)
+static void gauss_legendre(int n, std::vector<long double>& x, std::vector<long double>& w) {
+  x.assign(n, 0.0L);
+  w.assign(n, 0.0L);
+  const long double pi = 3.141592653589793238462643383279502884L;
+  for (int i = 0; i < (n + 1) / 2; ++i) {
+    long double z = cosl(pi * (i + 0.75L) / (n + 0.5L)), pp = 0.0L;
+    for (int it = 0; it < 100; ++it) {
+      long double p1 = 1.0L, p2 = 0.0L;
+      for (int j = 1; j <= n; ++j) {
+        const long double p3 = p2;
+        p2 = p1;
+        p1 = ((2.0L * j - 1.0L) * z * p2 - (j - 1.0L) * p3) / j;
+      }
+      pp = n * (z * p1 - p2) / (z * z - 1.0L);
+      const long double dz = p1 / pp;
+      z -= dz;
+      if (fabsl(dz) < 1e-19L) break;
+    }
+    x[i] = -z;
+    x[n - 1 - i] = z;
+    w[i] = w[n - 1 - i] = 2.0L / ((1.0L - z * z) * pp * pp);
+  }
+}
+
+// normalised Y_l^0 at x = cos(colat), l < n (long double)
+static void ylm0_row(long double xv, int n, long double* y) {
+  const long double pi = 3.141592653589793238462643383279502884L;
+  long double pm1 = 1.0L, pc = xv;
+  for (int l = 0; l < n; ++l) {
+    long double P;
+    if (l == 0) {
+      P = 1.0L;
+    } else if (l == 1) {
+      P = xv;
+    } else {
+      const long double pn = ((2 * l - 1) * xv * pc - (l - 1) * pm1) / l;
+      pm1 = pc;
+      pc = pn;
+      P = pn;
+    }
+    y[l] = sqrtl((2.0L * l + 1.0L) / (4.0L * pi)) * P;
+  }
+}
+
+static int os_cuts(temx_plan* pl, bool sub, int nsub, const int2** out) {
+  if (!sub) return class_cuts(pl, nsub, out, true);
+  auto it = pl->csplits_s.find(nsub);
+  if (it == pl->csplits_s.end()) {
+    std::vector<int> cut((size_t)2 * (nsub + 1));
+    int g = 0;
+    for (int k = 0; k <= nsub; ++k) {
+      const int64_t b = pl->sbatches * k / nsub;
+      while (g < pl->sgroups && pl->sgbatch0[(size_t)g] < b) ++g;
+      if (k == nsub) g = (int)pl->sgroups;
+      cut[(size_t)2 * k] = pl->sgbatch0[(size_t)g];
+      cut[(size_t)2 * k + 1] = g;
+    }
+    DevBuf b;
+    if (int rc = upload(b, cut.data(), cut.size() * sizeof(int))) return rc;
+    it = pl->csplits_s.emplace(nsub, b).first;
+  }
+  *out = static_cast<const int2*>(it->second.p);
+  return TEMX_OK;
+}
+
+// tables that depend on the grid and L only (built once per plan, at the first eligible temx_plan_set_tem)
+static int build_os_tables(temx_plan* pl) {
+  if (pl->os_built) return TEMX_OK;
+  const int K = pl->K, L = pl->L;
+  const int KX = 2 * L + 1, TBX = (L + 1 + 3) / 4;
+  const int KR = std::min(16, K);
+  pl->KX = KX;
+  pl->TBX = TBX;
+  pl->KR = KR;
+  int rc;
+  // basis up to degree 2L at the class latitudes, Y basis (no re-orthogonalisation: these are raw projections)
+  {
+    std::vector<double> nx((size_t)8 * TBX + 8, 0.0);
+    for (int l = 0; l < KX; ++l) nx[(size_t)l] = std::sqrt((2.0 * l + 1.0) / (4.0 * M_PI));
+    DevBuf nd;
+    if ((rc = upload(nd, nx.data(), nx.size() * 8))) return rc;
+    rc = pl->ycx.ensure((size_t)(pl->cgroups + 1) * 2 * TBX * 16 * 8);
+    if (!rc) {
+      hipLaunchKernelGGL(cls_basis_kernel<512>, dim3((unsigned)((pl->cls_npad + 255) / 256)), dim3(256), 0, 0, pl->xc.d(),
+                         pl->ncls, pl->cls_npad, KX, TBX, nd.d(), (const double*)nullptr, pl->ycx.d());
+      // subsample of class-groups for the reference fit: every S-th group, its batches copied
+      const int64_t S = std::max<int64_t>(1, std::min<int64_t>(32, pl->cgroups / 256));
+      std::vector<int> crow_s;
+      std::vector<double> xc_s;
+      pl->sgbatch0.clear();
+      for (int64_t gi = 0; gi < pl->cgroups; gi += S) {
+        pl->sgbatch0.push_back((int)(crow_s.size() / (4 * CLS_MB)));
+        const size_t e0 = (size_t)pl->gbatch0[(size_t)gi] * 4 * CLS_MB, e1 = (size_t)pl->gbatch0[(size_t)gi + 1] * 4 * CLS_MB;
+        crow_s.insert(crow_s.end(), pl->h_crow.begin() + e0, pl->h_crow.begin() + e1);
+        for (int k = 0; k < 4; ++k) xc_s.push_back(pl->h_xc[(size_t)gi * 4 + k]);
+      }
+      pl->sgroups = (int64_t)pl->sgbatch0.size();
+      pl->sbatches = (int64_t)(crow_s.size() / (4 * CLS_MB));
+      pl->sgbatch0.push_back((int)pl->sbatches);
+      crow_s.resize(crow_s.size() + (size_t)CLS_PADB * 4 * CLS_MB, (int)0x80000000);
+      xc_s.resize(xc_s.size() + 4, 0.0);
+      DevBuf xs;
+      if (!(rc = upload(pl->crow_s, crow_s.data(), crow_s.size() * sizeof(int))) && !(rc = upload(xs, xc_s.data(), xc_s.size() * 8)) &&
+          !(rc = pl->ycx_s.ensure((size_t)(pl->sgroups + 1) * 2 * TBX * 16 * 8))) {
+        const int64_t np = (pl->sgroups + 1) * 4;
+        // classes beyond the real ones in the last group of the full table have count 0 and x = 0: harmless rows
+        hipLaunchKernelGGL(cls_basis_kernel<512>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, 0, xs.d(), pl->sgroups * 4,
+                           np, KX, TBX, nd.d(), (const double*)nullptr, pl->ycx_s.d());
+      }
+      hipError_t e = hipDeviceSynchronize();
+      xs.release();
+      if (!rc && e != hipSuccess) rc = fail(TEMX_EHIP, "extended class basis failed: %s", hipGetErrorString(e));
+      // Gram matrix of the subsample, degree < KR, and its inverse
+      if (!rc) {
+        std::vector<long double> y((size_t)KR);
+        std::vector<double> Gs((size_t)KR * KR, 0.0);
+        std::vector<long double> Gl((size_t)KR * KR, 0.0L);
+        for (int64_t gi = 0; gi < pl->cgroups; gi += S)
+          for (int k = 0; k < 4; ++k) {
+            const long double nN = pl->h_cnt[(size_t)gi * 8 + k], nS = pl->h_cnt[(size_t)gi * 8 + 4 + k];
+            if (nN + nS == 0.0L) continue;
+            ylm0_row((long double)pl->h_xc[(size_t)gi * 4 + k], KR, y.data());
+            for (int l = 0; l < KR; ++l)
+              for (int m = 0; m < KR; ++m) Gl[(size_t)l * KR + m] += (nN + (((l + m) & 1) ? -nS : nS)) * y[l] * y[m];
+          }
+        for (size_t i = 0; i < Gs.size(); ++i) Gs[i] = (double)Gl[i];
+        std::vector<long double> Li;
+        std::vector<double> Gi((size_t)KR * KR);
+        if (spd_factor(Gs.data(), KR, Li) != 0)
+          rc = fail(TEMX_ERANK, "the subsample of latitude classes does not determine a degree-%d reference", KR - 1);
+        else {
+          inverse_from_factor(Li, KR, Gi.data());
+          rc = upload(pl->Gsinv, Gi.data(), Gi.size() * 8);
+        }
+      }
+    }
+    nd.release();
+    if (rc) return rc;
+  }
+  // Gauss-Legendre nodes for the transform form of the product linearisation (exact for degree 4L)
+  {
+    const int nq = 2 * L + 2;
+    pl->NQ = nq;
+    std::vector<long double> xq, wq;
+    gauss_legendre(nq, xq, wq);
+    std::vector<long double> row((size_t)KX);
+    std::vector<double> Yq((size_t)nq * KX), w2((size_t)nq);
+    const long double twopi = 2.0L * 3.141592653589793238462643383279502884L;
+    for (int q = 0; q < nq; ++q) {
+      ylm0_row(xq[(size_t)q], KX, row.data());
+      for (int k = 0; k < KX; ++k) Yq[(size_t)q * KX + k] = (double)row[(size_t)k];
+      w2[(size_t)q] = (double)(twopi * wq[(size_t)q]);
+    }
+    if ((rc = upload(pl->gaunt, Yq.data(), Yq.size() * 8))) return rc;       // (Yq[q][k])
+    if ((rc = upload(pl->wq2, w2.data(), w2.size() * 8))) return rc;
+  }
+  // Gx[l][k] = sum over the native columns of Y_l Y_k, l < K, k < KX (per latitude class)
+  {
+    std::vector<double> Gx((size_t)K * KX, 0.0), yy((size_t)KX);
+    std::vector<long double> y((size_t)KX);
+    for (int64_t ci = 0; ci < pl->ncls; ++ci) {
+      const int64_t gi = ci >> 2;
+      const int k4 = (int)(ci & 3);
+      const double nN = pl->h_cnt[(size_t)gi * 8 + k4], nS = pl->h_cnt[(size_t)gi * 8 + 4 + k4];
+      ylm0_row((long double)pl->h_xc[(size_t)ci], KX, y.data());
+      for (int k = 0; k < KX; ++k) yy[(size_t)k] = (double)y[(size_t)k];
+      const double se = nN + nS, so = nN - nS;
+      for (int l = 0; l < K; ++l) {
+        const double yl = yy[(size_t)l];
+        double* row = &Gx[(size_t)l * KX];
+        for (int k = (l & 1); k < KX; k += 2) row[k] += se * yl * yy[(size_t)k];        // l + k even
+        for (int k = 1 - (l & 1); k < KX; k += 2) row[k] += so * yl * yy[(size_t)k];    // l + k odd
+      }
+    }
+    if ((rc = upload(pl->Gx, Gx.data(), Gx.size() * 8))) return rc;
+  }
+  pl->os_built = true;
+  return TEMX_OK;
+}
+
+template <typename T>
+static int launch_sweep_os_t(temx_plan* pl, const FieldPtrs<4>& fp, bool sub, const double* rho, double* partial,
+                             const Split& sp, hipStream_t st) {
+  const int2* cuts = nullptr;
+  if (int rc = os_cuts(pl, sub, sp.nsplit, &cuts)) return rc;
+  dim3 grid(sp.grid), block(256);
+  constexpr int NBR = 2;
+  constexpr int PDv = sizeof(T) == 4 ? 4 : 2;
+  const int64_t KD4 = (int64_t)4 * pl->KX * pl->D;
+  double* px = partial;
+  double* pp = partial + (int64_t)sp.nsplit * KD4;
+#define TEMX_LOS(TBSv, TBXv)                                                                                        \
+  do {                                                                                                              \
+    auto kern = sweep_os_kernel<T, TBSv, TBXv, NBR, PDv>;                                                           \
+    const size_t lds = ((size_t)4 * 2 * TBXv * 16 + (size_t)4 * 4 * 2 * NBR * 64 + (size_t)4 * 3 * 2 * TBSv * 64) * 8; \
+    static std::atomic<uint64_t> attr_set{0};                                                                       \
+    if (int rc_ = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(kern), (int)lds)) return rc_;   \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->D, pl->K, pl->KX, sub ? pl->ycx_s.d() : pl->ycx.d(),     \
+                       static_cast<const int4*>(sub ? pl->crow_s.p : pl->crow.p), cuts, pl->colscale.d(), rho,      \
+                       pl->KR, px, pp, sp.nsplit, sp.ndt);                                                          \
+  } while (0)
+  if (pl->TBS == 7 && pl->TBX == 13) TEMX_LOS(7, 13);
+  else if (pl->TBS == 4 && pl->TBX == 8) TEMX_LOS(4, 8);
+  else if (pl->TBS == 2 && pl->TBX == 4) TEMX_LOS(2, 4);
+  else return fail(TEMX_EUNSUPPORTED, "single-sweep form: no instantiation for L = %d", pl->L);
+#undef TEMX_LOS
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+static bool os_supported(const temx_plan* pl) {
+  if (!pl->cls || pl->large || pl->weighted || !pl->qbasis || pl->h_crow.empty()) return false;
+  const int tbx = (pl->L + 1 + 3) / 4;
+  return (pl->TBS == 7 && tbx == 13) || (pl->TBS == 4 && tbx == 8) || (pl->TBS == 2 && tbx == 4);
+}
+
+static int tem_run_os(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, double* results, double* zonal, void* stream) {
+  hipStream_t st = S_(stream);
+  int rc;
+  const int64_t D = pl->D;
+  const int64_t KD4 = (int64_t)4 * pl->KX * D, KD3 = (int64_t)3 * pl->K * D;
+  pl->op_valid = pl->c4_valid = pl->tq_valid = false;       // no class sums on this path
+  // 1. reference: the same sweep over the subsample with a zero reference, degree < KR fit
+  rc = dtype == TEMX_F64 ? launch_sweep_os_t<double>(pl, fp, true, pl->rho0.d(), pl->partial.d(), pl->sp_os_s, st)
+                         : launch_sweep_os_t<float>(pl, fp, true, pl->rho0.d(), pl->partial.d(), pl->sp_os_s, st);
+  if (rc) return rc;
+  if ((rc = launch_reduce(pl, pl->partial.d(), pl->sp_os_s.nsplit, KD4, pl->Axs.d(), st))) return rc;
+  hipLaunchKernelGGL(os_ref_solve_kernel, dim3((unsigned)((D + 255) / 256), 4), dim3(256), 0, st, pl->Axs.d(), pl->KX, pl->KR, D,
+                     pl->Gsinv.d(), pl->rho.d());
+  HIPCHK(hipGetLastError());
+  // 2. the sweep
+  TimedLaunch tl{};
+  time_begin(pl, 0, st, tl);
+  rc = dtype == TEMX_F64 ? launch_sweep_os_t<double>(pl, fp, false, pl->rho.d(), pl->partial.d(), pl->sp_os, st)
+                         : launch_sweep_os_t<float>(pl, fp, false, pl->rho.d(), pl->partial.d(), pl->sp_os, st);
+  time_end(pl, 0, st, tl);
+  if (rc) return rc;
+  if ((rc = launch_reduce(pl, pl->partial.d(), pl->sp_os.nsplit, KD4, pl->Ax.d(), st))) return rc;
+  if ((rc = launch_reduce(pl, pl->partial.d() + (int64_t)pl->sp_os.nsplit * KD4, pl->sp_os.nsplit, KD3, pl->Pp.d(), st))) return rc;
+  // 3. linearisation: raw sums of the fields and of the eddy products in the plan's basis
+  {
+    TimedLaunch t2{};
+    time_begin(pl, 1, st, t2);
+    const size_t lds = os_contract_lds(pl->K, pl->KX, pl->NQ) * 8;
+    static std::atomic<uint64_t> attr_set{0};
+    if ((rc = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(os_contract_kernel), 160 * 1024))) return rc;
+    hipLaunchKernelGGL(os_contract_kernel, dim3((unsigned)((D + OSC - 1) / OSC)), dim3(256), lds, st, pl->Ax.d(), pl->Pp.d(),
+                       pl->rho.d(), pl->K, pl->KX, pl->KR, pl->NQ, D, pl->T.d(), pl->Ginv.d(), pl->G.d(), pl->Gx.d(),
+                       pl->gaunt.d(), pl->wq2.d(), pl->B4.d(), pl->B3.d());
+    HIPCHK(hipGetLastError());
+    time_end(pl, 1, st, t2);
+  }
+  // 4. as after stage 2: coefficients and zonal means of the four fields, then the epilogue
+  if ((rc = launch_solve(pl, pl->B4.d(), 4, D, pl->C4.d(), pl->zb.d(), st))) return rc;
+  pl->c4_valid = true;
+  return temx_tem_stage3(pl, pl->B3.d(), results, zonal, stream);
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -1317,7 +1595,10 @@ void temx_plan_destroy(temx_plan* pl) {
   pl->pbuf.release();
   pl->gblk.release();
   pl->ypblk.release();
-  for (DevBuf* b : {&pl->T, &pl->Qp, &pl->GinvA, &pl->G2, &pl->xo, &pl->xc}) b->release();
+  for (DevBuf* b : {&pl->T, &pl->Qp, &pl->GinvA, &pl->G2, &pl->xo, &pl->xc, &pl->ycx, &pl->ycx_s, &pl->crow_s, &pl->rho,
+                    &pl->rho0, &pl->gaunt, &pl->wq2, &pl->Gx, &pl->Gsinv, &pl->Ax, &pl->Axs, &pl->Pp})
+    b->release();
+  for (auto& kv : pl->csplits_s) kv.second.release();
   for (auto& kv : pl->csplits) kv.second.release();
   for (int w = 0; w < 2; ++w)
     for (auto& tl : pl->timed[w]) {
@@ -1490,6 +1771,9 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
 
       if ((rc = upload(pl->ccnt, ct.cnt.data(), ct.cnt.size() * 8))) return bail(rc);
       if ((rc = upload(pl->xc, ct.xc.data(), ct.xc.size() * 8))) return bail(rc);
+      pl->h_xc = ct.xc;
+      pl->h_cnt = ct.cnt;
+      pl->h_crow = ct.crow;
       pl->cls_npad = (ct.ngroups + 1) * 4;
       pl->gbatch0 = std::move(ct.gbatch0);
       pl->cgroups = ct.ngroups;
@@ -1812,6 +2096,7 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
   // (tem_ready fails) until the last allocation has succeeded
   pl->tem = false;
   pl->onepass = pl->lone = pl->op_valid = pl->xb_valid = pl->tq_valid = false;
+  pl->os_on = false;
   pl->nlev = nlev;
   pl->nt = nt;
   pl->D = (int64_t)nlev * nt;
@@ -1929,6 +2214,27 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
           if ((rc = pl->Pq.ensure((size_t)3 * pl->K * D * 8))) return rc;
           // TEM + one tracer in one sweep: the four waves of a workgroup share a d-tile (one workgroup per CU)
           pl->sp_copw = choose_split(D, std::max<int64_t>(1, cunits / 4), pl->num_cu, 1, 8);
+          // single-sweep form of temx_tem_run (no class-sum stream): TEMX_SINGLE_SWEEP=1
+          {
+            const char* es = getenv("TEMX_SINGLE_SWEEP");
+            if (es && es[0] == '1' && os_supported(pl)) {
+              if ((rc = build_os_tables(pl))) return rc;
+              pl->sp_os = choose_split(D, cunits, pl->num_cu, 4, 8);
+              pl->sp_os_s = choose_split(D, std::max<int64_t>(1, pl->sbatches / 4), pl->num_cu, 4, 2);
+              const size_t per = ((size_t)4 * pl->KX + 3 * pl->K) * D * 8;
+              if ((rc = pl->partial.ensure(std::max((size_t)std::max(pl->sp_os.nsplit, pl->sp_os_s.nsplit) * per, pl->partial.bytes)))) return rc;
+              if ((rc = pl->Ax.ensure((size_t)4 * pl->KX * D * 8))) return rc;
+              if ((rc = pl->Axs.ensure((size_t)4 * pl->KX * D * 8))) return rc;
+              if ((rc = pl->Pp.ensure((size_t)3 * pl->K * D * 8))) return rc;
+              if ((rc = pl->rho.ensure((size_t)4 * pl->KR * D * 8))) return rc;
+              if ((rc = pl->rho0.ensure((size_t)4 * pl->KR * D * 8))) return rc;
+              HIPCHK(hipMemset(pl->rho0.p, 0, pl->rho0.bytes));
+              const int2* cu = nullptr;
+              if ((rc = os_cuts(pl, false, pl->sp_os.nsplit, &cu))) return rc;
+              if ((rc = os_cuts(pl, true, pl->sp_os_s.nsplit, &cu))) return rc;
+              pl->os_on = true;
+            }
+          }
         }
       }
     }
@@ -2155,6 +2461,12 @@ int temx_tem_run(temx_plan* pl, const void* ua, const void* va, const void* ta, 
                  int dtype, double* results, double* zonal, void* stream) {
   int rc = tem_ready(pl);
   if (rc) return rc;
+  if (pl->os_on) {
+    if (!ua || !va || !ta || !wap || !results) return fail(TEMX_EINVAL, "null argument");
+    if (dtype != TEMX_F64 && dtype != TEMX_F32) return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
+    HIPCHK(hipSetDevice(pl->device));
+    return tem_run_os(pl, four(ua, va, ta, wap), dtype, results, zonal, stream);
+  }
   if ((rc = temx_tem_stage1(pl, ua, va, ta, wap, dtype, pl->B4.d(), stream))) return rc;
   if (temx_plan_one_pass(pl))
     rc = temx_tem_stage2_from_sums(pl, pl->B4.d(), pl->B3.d(), stream);

@@ -265,6 +265,39 @@ int run(int64_t N, int64_t D, int reps, const char* only) {
   };
   add_w(std::integral_constant<int, sizeof(T) == 8 ? 2 : 4>{});
   add_w(std::integral_constant<int, sizeof(T) == 8 ? 3 : 6>{});
+#ifdef LAB_OS
+  // the store-free single sweep (timing only here: random basis and reference tables)
+  {
+    constexpr int TBX = 13, KX = 101, K4r = 52;
+    static double *ycx = nullptr, *rho = nullptr, *px = nullptr, *pp = nullptr;
+    if (!ycx) {
+      std::vector<double> h((size_t)(ng + 1) * 2 * TBX * 16);
+      for (auto& v : h) v = std::generate_canonical<double, 53>(gen) - 0.5;
+      ycx = to_dev(h);
+      std::vector<double> r((size_t)4 * K4r * D);
+      for (auto& v : r) v = std::generate_canonical<double, 53>(gen) - 0.5;
+      rho = to_dev(r);
+      CHK(hipMalloc(&px, (size_t)16 * 4 * KX * D * 8));
+      CHK(hipMalloc(&pp, (size_t)16 * 3 * K * D * 8));
+    }
+    auto add_os = [&](auto nbrc, auto pdc) {
+      constexpr int NBR = decltype(nbrc)::value, PD = decltype(pdc)::value;
+      Split sp = choose_split(D, cunits, 256, 4, 8);
+      int2* cuts = reinterpret_cast<int2*>(to_dev(group_cuts(gb0, sp.nsplit)));
+      const size_t ldsb = ((size_t)4 * 2 * TBX * 16 + (size_t)4 * 4 * 2 * NBR * 64 + (size_t)4 * 3 * 2 * TBS * 64) * 8;
+      auto kern = sweep_os_kernel<T, TBS, TBX, NBR, PD>;
+      CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+      double *ycx_ = ycx, *rho_ = rho, *px_ = px, *pp_ = pp;
+      vars.push_back({"os    ONE sweep, no class-sum stream: 4 x 26 + 3 x 14 accumulators, reference blocks " + std::to_string(NBR) +
+                      ", PD=" + std::to_string(PD), 0, [=](double*) {
+        hipLaunchKernelGGL(kern, dim3(sp.grid), dim3(256), ldsb, 0, fp, D, K, KX, ycx_, reinterpret_cast<const int4*>(d_crow), cuts,
+                           d_cs, rho_, K4r, px_, pp_, sp.nsplit, sp.ndt); }});
+    };
+    add_os(std::integral_constant<int, 2>{}, std::integral_constant<int, sizeof(T) == 8 ? 2 : 4>{});
+    add_os(std::integral_constant<int, 2>{}, std::integral_constant<int, sizeof(T) == 8 ? 3 : 6>{});
+    add_os(std::integral_constant<int, 3>{}, std::integral_constant<int, sizeof(T) == 8 ? 3 : 6>{});
+  }
+#endif
 #ifdef LAB_FUSED
   // TEM + one tracer in one sweep: five fields, ten projections (its outputs are not compared here: the
   // library's tests do that; slabs differ from the reference kernel's seven)
@@ -327,7 +360,8 @@ int run(int64_t N, int64_t D, int reps, const char* only) {
     v.launch(cso);
     CHK(hipGetLastError());
     CHK(hipDeviceSynchronize());
-    hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, 0, partial, v.nsplit, nB, have_ref ? B_t : B_ref);
+    if (v.nsplit > 0)
+      hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, 0, partial, v.nsplit, nB, have_ref ? B_t : B_ref);
     float best = 1e9f, sum = 0.f;
     for (int r = 0; r < reps; ++r) {
       CHK(hipEventRecord(ea));
