@@ -134,6 +134,8 @@ def main():
                     help="force the generic sweeps (neither latitude classes nor mirror pairing)")
     ap.add_argument("--two-pass", action="store_true",
                     help="latitude-class sweeps in their two-pass form (fields read twice)")
+    ap.add_argument("--class-sums", action="store_true",
+                    help="one-pass class path in its class-sum form (sweep + flux kernel) instead of the single sweep")
     ap.add_argument("--no-classes", action="store_true",
                     help="do not use the latitude-class sweeps (mirror-paired sweeps on a symmetric grid)")
     ap.add_argument("--no-extras", action="store_true",
@@ -148,6 +150,8 @@ def main():
     args = ap.parse_args()
     if args.two_pass:
         os.environ["TEMX_TWO_PASS"] = "1"
+    if args.class_sums:
+        os.environ["TEMX_SINGLE_SWEEP"] = "0"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -274,7 +278,7 @@ def main():
                                "ten GM16 Table-A1 outputs" % (ne, ncol, nlev, nt, "GPU" if scaling == "weak" else "job"),
                    "shard": args.shard if (world > 1 or use_ncol) else "none", "ncol": int(ncol), "nlev": nlev, "nt": nt,
                    "sweeps": ("generic", "mirror-paired", "latitude-class")[plan.sweep_mode]
-                             + (", one pass" if plan.one_pass else ""),
+                             + (", single sweep" if getattr(plan, "single_sweep", False) else (", one pass" if plan.one_pass else "")),
                    "mirror_paired_sweeps": bool(plan.paired)},
         # per-step HIP-event times of the same K steps (this rank): SURVEY 8(d) quotes the median of >= 20
         "ms_per_step_median": median_ms, "ms_per_step_min": step_ms[0], "ms_per_step_max": step_ms[-1],
@@ -300,8 +304,12 @@ def main():
         if plan.one_pass and nproj:
             # one-pass class path: the dominant kernel is sweep 1 (the only read of the fields)
             gbs_p = 4 * esize * pts_rank / (proj_ms * 1e-3) / 1e9
-            rec["roofline"] = {"kernel": "sweep_op_kernel (sweep 1 of the one-pass class path: theta + class sums of the fields, "
-                                         "centred class co-moments of u v, u omega, v theta + 7 class projections)",
+            single = bool(getattr(plan, "single_sweep", False))
+            rec["roofline"] = {"kernel": ("sweep_os_kernel (the single sweep: theta, class sums of the four fields minus a low-degree "
+                                          "reference projected to degree 2L, their three products to degree L; no class-sum stream)"
+                                          if single else
+                                          "sweep_op_kernel (sweep 1 of the one-pass class path: theta + class sums of the fields, "
+                                          "centred class co-moments of u v, u omega, v theta + 7 class projections)"),
                                "bound": "hbm", "achieved": gbs_p, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": gbs_p / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": proj_ms,
                                "launches": nproj,
@@ -309,8 +317,14 @@ def main():
                                               "%d points per launch; the kernel also stores the 4 field sums of every "
                                               "latitude-class side (8 x 512 B per class-group and d-tile, see traffic)"
                                               % (esize, pts_rank)}
-            rec["roofline_flux"] = {"kernel": "flux_cls_kernel (class reconstructions, n (m_u - ub)(m_v - vb) per class side, "
-                                              "3 class projections)", "avg_launch_ms": eddy_ms, "launches": neddy}
+            rec["roofline_flux"] = {"kernel": ("os_contract_kernel (eddy-product sums from the projections: Legendre product "
+                                               "linearisation on Gauss-Legendre nodes)" if single else
+                                               "flux_cls_kernel (class reconstructions, n (m_u - ub)(m_v - vb) per class side, "
+                                               "3 class projections)"), "avg_launch_ms": eddy_ms, "launches": neddy}
+            if single:
+                rec["roofline"]["algorithmic"] = ("4 fields x %d B per grid point (the one compulsory read of u, v, T, omega) x %d "
+                                                  "points per launch; nothing else of that order is read or written"
+                                                  % (esize, pts_rank))
         elif plan.sweep_mode == 2:
             gbs_e = 4 * esize * pts_rank / (eddy_ms * 1e-3) / 1e9
             rec["roofline"] = {"kernel": "eddy_cls_kernel (class reconstructions + eddies + products + class projections)",
@@ -343,7 +357,7 @@ def main():
                                                          "passes of this command (tools/profile_session.sh), not this run")
             except Exception:
                 pass
-    if nproj and not rec["config"]["sweeps"].endswith("one pass"):
+    if nproj and not (rec["config"]["sweeps"].endswith("one pass") or rec["config"]["sweeps"].endswith("single sweep")):
         gbs = 4 * esize * pts_rank / (proj_ms * 1e-3) / 1e9
         rec["roofline_project"] = {"kernel": "project kernel (theta + 4 projections)", "bound": "hbm",
                                    "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -397,7 +411,7 @@ def main():
                     "ms_per_step": dt2 * 1e3, "grid_points_per_s": pts2 / dt2, "reps": reps, "ncol": int(lat2.size),
                     "plan_symmetry": not generic,
                     "sweeps": ("generic", "mirror-paired", "latitude-class")[p2.sweep_mode]
-                              + (", one pass" if p2.one_pass else ""),
+                              + (", single sweep" if getattr(p2, "single_sweep", False) else (", one pass" if p2.one_pass else "")),
                     "frac_of_fp64_roofline": pts2 / dt2 / (PEAK_F64_TFLOPS * 1e12 / FLOPS_PER_PT)}
                 p2.close()
                 del f2, o2

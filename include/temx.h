@@ -155,6 +155,15 @@ int temx_plan_sweep_mode(const temx_plan* plan);
  * 8 x 512 B per class-group and d-tile; TEMX_TWO_PASS=1 in the environment disables, TEMX_ONE_PASS=1
  * lifts the size threshold. */
 int temx_plan_one_pass(const temx_plan* plan);
+/* 1 when temx_tem_run takes the SINGLE-SWEEP form (one-pass class path on a grid with >= 2048 class-groups,
+ * L <= 51; TEMX_SINGLE_SWEEP=0 / =1 in the environment disables / forces where possible): no per-class sums
+ * are stored at all.  One sweep projects the four fields -- minus a band-limited reference of degree <= 15
+ * fitted to a subsample of the latitude classes in a short pre-pass -- up to degree 2L, and their three
+ * products up to degree L; the eddy-product sums then follow from the Legendre product linearisation
+ * (sum_i Y_l abar b = a bilinear form of the coefficients of abar and of the degree-2L projection of b,
+ * evaluated on Gauss-Legendre nodes).  Same results to ~1e-12; the staged, all-reducible entry points
+ * (temx_tem_stage1 / stage2_from_sums) and the tracer's one-pass stages keep the class-sum form. */
+int temx_plan_single_sweep(const temx_plan* plan);
 
 int temx_get_matrix(temx_plan* plan, int which, double* dst, void* stream);
 

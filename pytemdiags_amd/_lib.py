@@ -45,6 +45,7 @@ SIGNATURES = [
     ("temx_plan_is_paired", _i, [_vp]),
     ("temx_plan_sweep_mode", _i, [_vp]),
     ("temx_plan_one_pass", _i, [_vp]),
+    ("temx_plan_single_sweep", _i, [_vp]),
     ("temx_get_matrix", _i, [_vp, _i, _vp, _vp]),
     ("temx_project", _i, [_vp, _vp, _i, _i64, _vp, _vp]),
     ("temx_zonal_mean", _i, [_vp, _vp, _i, _i64, _vp, _i, _vp]),

@@ -1372,7 +1372,8 @@ static int os_cuts(temx_plan* pl, bool sub, int nsub, const int2** out) {
 static int build_os_tables(temx_plan* pl) {
   if (pl->os_built) return TEMX_OK;
   const int K = pl->K, L = pl->L;
-  const int KX = 2 * L + 1, TBX = (L + 1 + 3) / 4;
+  const int KX = 2 * L + 1;
+  const int TBX = pl->TBS == 7 ? 13 : (pl->TBS == 4 ? 8 : 4);      // blocks per parity of the degree-2L basis (zero padded)
   const int KR = std::min(16, K);
   pl->KX = KX;
   pl->TBX = TBX;
@@ -1515,8 +1516,8 @@ static int launch_sweep_os_t(temx_plan* pl, const FieldPtrs<4>& fp, bool sub, co
 
 static bool os_supported(const temx_plan* pl) {
   if (!pl->cls || pl->large || pl->weighted || !pl->qbasis || pl->h_crow.empty()) return false;
-  const int tbx = (pl->L + 1 + 3) / 4;
-  return (pl->TBS == 7 && tbx == 13) || (pl->TBS == 4 && tbx == 8) || (pl->TBS == 2 && tbx == 4);
+  const int tbx = (pl->L + 1 + 3) / 4;          // blocks of 4 even harmonics up to degree 2L
+  return (pl->TBS == 7 && tbx <= 13) || (pl->TBS == 4 && tbx <= 8) || (pl->TBS == 2 && tbx <= 4);
 }
 
 static int tem_run_os(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, double* results, double* zonal, void* stream) {
@@ -1833,6 +1834,8 @@ int temx_plan_sweep_mode(const temx_plan* pl) {
 int temx_plan_one_pass(const temx_plan* pl) {
   return pl && ((pl->cls && pl->onepass) || (pl->lcls && pl->lone)) ? 1 : 0;
 }
+
+int temx_plan_single_sweep(const temx_plan* pl) { return pl && pl->os_on ? 1 : 0; }
 
 // G2 (device) = Q^T Q over this plan's rows, through the projection sweep (A = Q, D = K)
 static int gram_of_q(temx_plan* pl) {
@@ -2214,11 +2217,19 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
           if ((rc = pl->Pq.ensure((size_t)3 * pl->K * D * 8))) return rc;
           // TEM + one tracer in one sweep: the four waves of a workgroup share a d-tile (one workgroup per CU)
           pl->sp_copw = choose_split(D, std::max<int64_t>(1, cunits / 4), pl->num_cu, 1, 8);
-          // single-sweep form of temx_tem_run (no class-sum stream): TEMX_SINGLE_SWEEP=1
+          // single-sweep form of temx_tem_run (no class-sum stream), the default where the one-pass path runs
+          // and the grid has enough latitude classes for the reference fit; TEMX_SINGLE_SWEEP=0 keeps the
+          // class-sum form, =1 also takes it on small grids
           {
             const char* es = getenv("TEMX_SINGLE_SWEEP");
-            if (es && es[0] == '1' && os_supported(pl)) {
-              if ((rc = build_os_tables(pl))) return rc;
+            const bool off = es && es[0] == '0', forced = es && es[0] == '1';
+            bool want = !off && os_supported(pl) && (forced || pl->cgroups >= 2048);
+            if (want) {
+              rc = build_os_tables(pl);
+              if (rc == TEMX_ERANK) want = false;          // too few distinct latitudes in the subsample: class-sum form
+              else if (rc) return rc;
+            }
+            if (want) {
               pl->sp_os = choose_split(D, cunits, pl->num_cu, 4, 8);
               pl->sp_os_s = choose_split(D, std::max<int64_t>(1, pl->sbatches / 4), pl->num_cu, 4, 2);
               const size_t per = ((size_t)4 * pl->KX + 3 * pl->K) * D * 8;

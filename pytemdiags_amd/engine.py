@@ -60,6 +60,11 @@ class Plan:
         return bool(self.lib.temx_plan_one_pass(self._h))
 
     @property
+    def single_sweep(self):
+        """True when ``tem_run`` takes the single-sweep form: no class-sum stream (see include/temx.h)."""
+        return bool(self.lib.temx_plan_single_sweep(self._h))
+
+    @property
     def tracer_one_pass(self):
         """True when tracer runs should take the one-pass stages (``one_pass`` and TEMX_TRACER_ONE_PASS=1;
         the two-pass tracer stages measured faster, see include/temx.h)."""

@@ -7,7 +7,7 @@ int main(void) {
   const void* syms[] = {
       (const void*)temx_version, (const void*)temx_last_error, (const void*)temx_device_count,
       (const void*)temx_plan_create, (const void*)temx_plan_finalize, (const void*)temx_plan_refine, (const void*)temx_plan_set_weights,
-      (const void*)temx_plan_destroy, (const void*)temx_plan_is_paired, (const void*)temx_plan_sweep_mode, (const void*)temx_plan_one_pass,
+      (const void*)temx_plan_destroy, (const void*)temx_plan_is_paired, (const void*)temx_plan_sweep_mode, (const void*)temx_plan_one_pass, (const void*)temx_plan_single_sweep,
       (const void*)temx_get_matrix, (const void*)temx_project, (const void*)temx_zonal_mean,
       (const void*)temx_zonal_mean_from_sums, (const void*)temx_plan_set_tem, (const void*)temx_tem_stage1,
       (const void*)temx_tem_stage2, (const void*)temx_tem_stage2_from_sums, (const void*)temx_tem_stage3, (const void*)temx_tem_run,

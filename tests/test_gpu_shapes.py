@@ -672,3 +672,61 @@ def test_tem_and_tracer_in_one_sweep(force_one_pass, ne, nlev, nt, dtype, L):
         assert torch.equal(r3, res) and torch.equal(t3, tres)
     assert not plan.status()
     plan.close()
+
+
+@pytest.mark.parametrize("ne,nlev,nt,dtype,L", [
+    (16, 16, 8, np.float64, 50),     # D = 128
+    (12, 13, 5, np.float64, 50),     # D = 65: ragged last d-tile
+    (12, 30, 6, np.float32, 50),     # fp32 inputs
+    (12, 16, 5, np.float64, 28),     # TBS = 4: degree-2L basis of 8 blocks per parity
+    (10, 16, 5, np.float64, 12),     # TBS = 2
+    (10, 16, 5, np.float64, 40),     # TBS = 7 with a zero-padded degree-2L basis
+])
+def test_single_sweep_form(monkeypatch, ne, nlev, nt, dtype, L):
+    """The single-sweep form of temx_tem_run (include/temx.h, temx_plan_single_sweep): no class-sum stream, the
+    eddy-product sums from the Legendre product linearisation.  Against the oracle, against the class-sum
+    form on the same plan inputs, run to run bit for bit, and the tracer / eddy entry points that follow a
+    TEM run (tem_diagnostics.py:515-570)."""
+    from oracle import tem_oracle as orc
+    from pytemdiags_amd import _lib, engine, synth
+    import os
+    if any(os.environ.get(k) == "1" for k in ("TEMX_NO_SYM", "TEMX_NO_CLS", "TEMX_TWO_PASS", "TEMX_NO_QR")):
+        pytest.skip("the single-sweep form needs the one-pass class path on the re-orthogonalised basis")
+    lat, lon = synth.cubed_sphere_gll(ne)
+    plev = synth.pressure_levels(nlev)
+    f = synth.analytic_fields(lat, lon, plev, nt, seed=41, dtype=dtype)
+    q = synth.analytic_tracer(lat, lon, plev, nt).astype(dtype)
+    ref = orc.TEMOracle(*f, lat, plev, L=L, mode="factorised", q=[q])
+    d = [torch.as_tensor(x, device="cuda:0") for x in f]
+    dq = torch.as_tensor(q, device="cuda:0")
+    tol = 1e-10 if dtype == np.float64 else 2e-5
+    monkeypatch.setenv("TEMX_ONE_PASS", "1")
+    monkeypatch.setenv("TEMX_SINGLE_SWEEP", "1")
+    plan = engine.Plan(lat, ref.lat, L)
+    plan.set_tem(nlev, nt, plev * 100)
+    assert plan.one_pass and plan.single_sweep
+    res, zon = plan.tem_run(*d, want_zonal=True)
+    assert not plan.status()
+    for i, n in enumerate(_lib.RESULT_NAMES):
+        assert fieldnorm_err(res[i].cpu().numpy(), getattr(ref, n)()) <= tol, n
+    for i, n in enumerate(_lib.ZONAL_NAMES):
+        assert fieldnorm_err(zon[i].cpu().numpy(), getattr(ref, n)) <= tol, n
+    res2, _ = plan.tem_run(*d)
+    assert torch.equal(res, res2)                                   # fixed-order reductions
+    # what follows a TEM run works from its coefficients: native eddies, tracer (two-pass stages here)
+    ed = plan.tem_eddy(*d)
+    assert fieldnorm_err(ed["upvp"].cpu().numpy(), ref.upvp) <= tol
+    tres, _ = plan.tracer_run(dq, d[1], d[3])
+    for k, n in enumerate(_lib.TRACER_RESULT_NAMES):
+        assert fieldnorm_err(tres[k].cpu().numpy(), getattr(ref, n)(0)) <= tol, n
+    # the staged entry points keep the class-sum form and agree
+    B4 = plan.tem_stage1(*d)
+    r3, _ = plan.tem_stage3(plan.tem_stage2_from_sums(B4))
+    for i, n in enumerate(_lib.RESULT_NAMES):
+        assert float((r3[i] - res[i]).abs().max()) <= (1e-11 if dtype == np.float64 else 1e-5) * float(res[i].abs().max()), n
+    plan.close()
+    monkeypatch.setenv("TEMX_SINGLE_SWEEP", "0")
+    plan = engine.Plan(lat, ref.lat, L)
+    plan.set_tem(nlev, nt, plev * 100)
+    assert plan.one_pass and not plan.single_sweep
+    plan.close()

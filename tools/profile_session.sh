@@ -10,6 +10,7 @@ O=$REPO/gpurun_out
 mkdir -p "$O"
 python bench.py 2> "$O/bench_$R.err" | tail -n 1 > "$O/bench_$R.json"
 echo "bench default done"
+python bench.py --no-cpu-baseline --class-sums --also= 2>> "$O/bench_$R.err" | tail -n 1 > "$O/bench_${R}_classsums.json"
 python bench.py --no-cpu-baseline --two-pass 2>> "$O/bench_$R.err" | tail -n 1 > "$O/bench_${R}_twopass.json"
 python bench.py --no-cpu-baseline --no-classes 2>> "$O/bench_$R.err" | tail -n 1 > "$O/bench_${R}_paired.json"
 python bench.py --no-cpu-baseline --no-symmetry 2>> "$O/bench_$R.err" | tail -n 1 > "$O/bench_${R}_generic.json"
