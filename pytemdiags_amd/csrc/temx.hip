@@ -1390,7 +1390,7 @@ static int build_os_tables(temx_plan* pl) {
       hipLaunchKernelGGL(cls_basis_kernel<512>, dim3((unsigned)((pl->cls_npad + 255) / 256)), dim3(256), 0, 0, pl->xc.d(),
                          pl->ncls, pl->cls_npad, KX, TBX, nd.d(), (const double*)nullptr, pl->ycx.d());
       // subsample of class-groups for the reference fit: every S-th group, its batches copied
-      const int64_t S = std::max<int64_t>(1, std::min<int64_t>(32, pl->cgroups / 256));
+      const int64_t S = std::max<int64_t>(1, std::min<int64_t>(64, pl->cgroups / 192));
       std::vector<int> crow_s;
       std::vector<double> xc_s;
       pl->sgbatch0.clear();
@@ -1421,7 +1421,7 @@ static int build_os_tables(temx_plan* pl) {
         std::vector<long double> y((size_t)KR);
         std::vector<double> Gs((size_t)KR * KR, 0.0);
         std::vector<long double> Gl((size_t)KR * KR, 0.0L);
-        for (int64_t gi = 0; gi < pl->cgroups; gi += S)
+        for (int64_t gi = 0; gi < pl->cgroups; gi += S)   // (the same groups as above)
           for (int k = 0; k < 4; ++k) {
             const long double nN = pl->h_cnt[(size_t)gi * 8 + k], nS = pl->h_cnt[(size_t)gi * 8 + 4 + k];
             if (nN + nS == 0.0L) continue;
@@ -2472,7 +2472,12 @@ int temx_tem_run(temx_plan* pl, const void* ua, const void* va, const void* ta, 
                  int dtype, double* results, double* zonal, void* stream) {
   int rc = tem_ready(pl);
   if (rc) return rc;
-  if (pl->os_on) {
+  // (fp32 inputs keep the class-sum form: their records are a quarter of the traffic, not an eighth, but the rows
+  //  are read in 64-byte pieces either way and the heavier sweep measured slower -- ne240 x 128 x 1: 2.5 vs 2.2 ms --
+  //  unless TEMX_SINGLE_SWEEP=1 forces it)
+  const char* e_os = pl->os_on && dtype != TEMX_F64 ? getenv("TEMX_SINGLE_SWEEP") : nullptr;
+  const bool os_f32 = e_os && e_os[0] == '1';
+  if (pl->os_on && (dtype == TEMX_F64 || os_f32)) {
     if (!ua || !va || !ta || !wap || !results) return fail(TEMX_EINVAL, "null argument");
     if (dtype != TEMX_F64 && dtype != TEMX_F32) return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
     HIPCHK(hipSetDevice(pl->device));
