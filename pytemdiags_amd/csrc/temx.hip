@@ -12,6 +12,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <atomic>
 #include <vector>
 
@@ -1460,24 +1461,35 @@ static int build_os_tables(temx_plan* pl) {
     if ((rc = upload(pl->gaunt, Yq.data(), Yq.size() * 8))) return rc;       // (Yq[q][k])
     if ((rc = upload(pl->wq2, w2.data(), w2.size() * 8))) return rc;
   }
-  // Gx[l][k] = sum over the native columns of Y_l Y_k, l < K, k < KX (per latitude class)
+  // Gx[l][k] = sum over the native columns of Y_l Y_k, l < K, k < KX (per latitude class; host threads)
   {
-    std::vector<double> Gx((size_t)K * KX, 0.0), yy((size_t)KX);
-    std::vector<long double> y((size_t)KX);
-    for (int64_t ci = 0; ci < pl->ncls; ++ci) {
-      const int64_t gi = ci >> 2;
-      const int k4 = (int)(ci & 3);
-      const double nN = pl->h_cnt[(size_t)gi * 8 + k4], nS = pl->h_cnt[(size_t)gi * 8 + 4 + k4];
-      ylm0_row((long double)pl->h_xc[(size_t)ci], KX, y.data());
-      for (int k = 0; k < KX; ++k) yy[(size_t)k] = (double)y[(size_t)k];
-      const double se = nN + nS, so = nN - nS;
-      for (int l = 0; l < K; ++l) {
-        const double yl = yy[(size_t)l];
-        double* row = &Gx[(size_t)l * KX];
-        for (int k = (l & 1); k < KX; k += 2) row[k] += se * yl * yy[(size_t)k];        // l + k even
-        for (int k = 1 - (l & 1); k < KX; k += 2) row[k] += so * yl * yy[(size_t)k];    // l + k odd
-      }
-    }
+    const int nth = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::vector<double>> part((size_t)nth, std::vector<double>((size_t)K * KX, 0.0));
+    std::vector<std::thread> th;
+    for (int t = 0; t < nth; ++t)
+      th.emplace_back([&, t]() {
+        std::vector<double> yy((size_t)KX);
+        std::vector<long double> y((size_t)KX);
+        std::vector<double>& Gp = part[(size_t)t];
+        for (int64_t ci = t; ci < pl->ncls; ci += nth) {
+          const int64_t gi = ci >> 2;
+          const int k4 = (int)(ci & 3);
+          const double nN = pl->h_cnt[(size_t)gi * 8 + k4], nS = pl->h_cnt[(size_t)gi * 8 + 4 + k4];
+          ylm0_row((long double)pl->h_xc[(size_t)ci], KX, y.data());
+          for (int k = 0; k < KX; ++k) yy[(size_t)k] = (double)y[(size_t)k];
+          const double se = nN + nS, so = nN - nS;
+          for (int l = 0; l < K; ++l) {
+            const double yl = yy[(size_t)l];
+            double* row = &Gp[(size_t)l * KX];
+            for (int k = (l & 1); k < KX; k += 2) row[k] += se * yl * yy[(size_t)k];        // l + k even
+            for (int k = 1 - (l & 1); k < KX; k += 2) row[k] += so * yl * yy[(size_t)k];    // l + k odd
+          }
+        }
+      });
+    for (auto& x : th) x.join();
+    std::vector<double> Gx((size_t)K * KX, 0.0);
+    for (int t = 0; t < nth; ++t)          // fixed order: the same bits whatever the scheduling
+      for (size_t i = 0; i < Gx.size(); ++i) Gx[i] += part[(size_t)t][i];
     if ((rc = upload(pl->Gx, Gx.data(), Gx.size() * 8))) return rc;
   }
   pl->os_built = true;
