@@ -11,6 +11,10 @@ lat, lon = synth.cubed_sphere_gll(ne)
 plev = synth.pressure_levels(nlev)
 e = np.arange(-90, 91, 1.0); lat_zm = (e[1:] + e[:-1]) / 2
 f = engine.synth_fields(0, lat, lon, plev, nt, dtype=torch.float64, seed=0)
+if os.environ.get("PROBE_RANDOM") == "1":       # does the data matter for the sweep's time?
+    g = torch.Generator(device="cuda:0"); g.manual_seed(1)
+    for i, (b, a) in enumerate(((10.0, 20.0), (-3.0, 10.0), (250.0, 30.0), (0.05, 0.2))):
+        f[i].uniform_(b - a / 2, b + a / 2, generator=g)
 os.environ["TEMX_ONE_PASS"] = "1"
 out = {}
 for form in ("csum", "single"):
