@@ -18,9 +18,7 @@ if os.environ.get("PROBE_RANDOM") == "1":       # does the data matter for the s
 os.environ["TEMX_ONE_PASS"] = "1"
 out = {}
 for form in ("csum", "single"):
-    os.environ.pop("TEMX_SINGLE_SWEEP", None)
-    if form == "single":
-        os.environ["TEMX_SINGLE_SWEEP"] = "1"
+    os.environ["TEMX_SINGLE_SWEEP"] = "1" if form == "single" else "0"
     plan = engine.Plan(lat, lat_zm, 50)
     plan.set_tem(nlev, nt, plev * 100)
     res, zon = plan.tem_run(*f, want_zonal=True)
