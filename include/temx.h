@@ -162,7 +162,11 @@ int temx_plan_one_pass(const temx_plan* plan);
  * products up to degree L; the eddy-product sums then follow from the Legendre product linearisation
  * (sum_i Y_l abar b = a bilinear form of the coefficients of abar and of the degree-2L projection of b,
  * evaluated on Gauss-Legendre nodes).  Same results to ~1e-12; the staged, all-reducible entry points
- * (temx_tem_stage1 / stage2_from_sums) and the tracer's one-pass stages keep the class-sum form. */
+ * (temx_tem_stage1 / stage2_from_sums, temx_tracer_stage*) keep the class-sum form.  temx_tracer_run after
+ * such a temx_tem_run takes the tracer's own single sweep over (q, v, omega): it reuses the projections and
+ * references of v and omega the TEM run left in the plan -- the SAME va, wap must be handed over, as for the
+ * one-pass tracer stages -- and any temx_tem_stage1 / temx_plan_set_tem in between sends it back to the other
+ * forms.  fp32 inputs keep the class-sum forms. */
 int temx_plan_single_sweep(const temx_plan* plan);
 
 int temx_get_matrix(temx_plan* plan, int which, double* dst, void* stream);

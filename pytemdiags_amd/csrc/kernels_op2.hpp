@@ -812,12 +812,29 @@ __device__ __forceinline__ constexpr int symx_harm(int tb, int i) {
   return tb < TBX ? 2 * (4 * tb + i) : 2 * (4 * (tb - TBX) + i) + 1;
 }
 
-template <typename T, int TBS, int TBX, int NBR, int PD>
+// KIND 0: TEM     fields (u, v, T -> theta, omega), all four projected to degree 2L; products u v, u omega, v theta
+// KIND 1: tracer  fields (q, v, omega): only q is projected to degree 2L (the projections of v and omega are
+//                 those of the TEM run, whose references for v and omega must be handed over again); products q v, q omega
+template <int KIND> struct OsKind;
+template <> struct OsKind<0> {
+  static constexpr int NF = 4, NFX = 4, NP = 3, TF = 2, TP = 2;
+  __host__ __device__ static constexpr int pa(int k) { return k == 2 ? 1 : 0; }
+  __host__ __device__ static constexpr int pb(int k) { return k == 0 ? 1 : (k == 1 ? 3 : 2); }
+};
+template <> struct OsKind<1> {
+  static constexpr int NF = 3, NFX = 1, NP = 2, TF = -1, TP = -1;
+  __host__ __device__ static constexpr int pa(int) { return 0; }
+  __host__ __device__ static constexpr int pb(int k) { return k == 0 ? 1 : 2; }
+};
+
+template <typename T, int TBS, int TBX, int NBR, int PD, int KIND = 0>
 __global__ void __launch_bounds__(256, 1)
 sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restrict__ ycx,
                 const int4* __restrict__ crow, const int2* __restrict__ csplit,
                 const double* __restrict__ colscale, const double* __restrict__ rho, int K4,
                 double* __restrict__ px, double* __restrict__ pp, int nsplit, int ndt) {
+  using KD = OsKind<KIND>;
+  constexpr int NF = KD::NF, NFX = KD::NFX, NP = KD::NP;
   constexpr int NBX = 2 * TBX;                // blocks of the extended basis
   constexpr int YE = NBX * 16;
   constexpr int YJ = (YE + 63) / 64;
@@ -841,39 +858,38 @@ sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restr
   const uint32_t aoff_p = (uint32_t)(g * 4 + (lane & 3));
   const uint32_t aoff_r = (uint32_t)((lane & 3) * 4 + g);
   double* yst = lds + wave * YE;
-  double* cb = lds + 4 * YE + wave * (4 * 2 * NBR * 64) + lane;
-  double* apl = lds + 4 * YE + 4 * (4 * 2 * NBR * 64) + wave * (3 * 2 * TBS * 64) + lane;
-  const double sth = colscale != nullptr ? colscale[dcl] : 1.0;
+  double* cb = lds + 4 * YE + wave * (NF * 2 * NBR * 64) + lane;
+  double* apl = lds + 4 * YE + 4 * (NF * 2 * NBR * 64) + wave * (NP * 2 * TBS * 64) + lane;
+  const double sth = (KD::TF >= 0 && colscale != nullptr) ? colscale[dcl] : 1.0;
 #pragma unroll
-  for (int i = 0; i < 3 * 2 * TBS; ++i) apl[i * 64] = 0.0;
+  for (int i = 0; i < NP * 2 * TBS; ++i) apl[i * 64] = 0.0;
 #pragma unroll
-  for (int f = 0; f < 4; ++f)
+  for (int f = 0; f < NF; ++f)
 #pragma unroll
     for (int tb = 0; tb < 2 * NBR; ++tb) {   // (reference blocks: the first NBR even and the first NBR odd blocks)
       const int l = tb < NBR ? 2 * (4 * tb + g) : 2 * (4 * (tb - NBR) + g) + 1;
       const double v = rho[((int64_t)f * K4 + (l < K ? l : K - 1)) * D + dcl];
       cb[(f * 2 * NBR + tb) * 64] = l < K ? v : 0.0;
     }
-  const T* fb[4];
+  const T* fb[NF];
 #pragma unroll
-  for (int f = 0; f < 4; ++f) fb[f] = reinterpret_cast<const T*>(fp.p[f]) + dcl;
+  for (int f = 0; f < NF; ++f) fb[f] = reinterpret_cast<const T*>(fp.p[f]) + dcl;
 
-  double ax[4][NBX];
+  double ax[NFX][NBX];
 #pragma unroll
-  for (int f = 0; f < 4; ++f)
+  for (int f = 0; f < NFX; ++f)
 #pragma unroll
     for (int t = 0; t < NBX; ++t) ax[f][t] = 0.0;
-  using KD = OpKind<0>;
-  double s[4], q[3], x0[4], cnt = 0.0;
-  double sN[4], qN[3], x0N[4], cntN = 0.0;      // the finished northern side, still about its own origin
+  double s[NF], q[NP], x0[NF], cnt = 0.0;
+  double sN[NF], qN[NP], x0N[NF], cntN = 0.0;   // the finished northern side, still about its own origin
 #pragma unroll
-  for (int f = 0; f < 4; ++f) s[f] = x0[f] = sN[f] = x0N[f] = 0.0;
+  for (int f = 0; f < NF; ++f) s[f] = x0[f] = sN[f] = x0N[f] = 0.0;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) q[k] = qN[k] = 0.0;
+  for (int k = 0; k < NP; ++k) q[k] = qN[k] = 0.0;
   bool north_open = false, prev_south = false;
   const uint32_t D32 = (uint32_t)D;
 
-  T xb[PD][MB][4];
+  T xb[PD][MB][NF];
   int er[PD][MB];
   double ys[YJ];
   auto load_ys = [&](int gi) __attribute__((always_inline)) {
@@ -887,14 +903,14 @@ sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restr
     for (int j = 0; j < MB; ++j) {
       const uint64_t off = (uint64_t)(uint32_t)(er[P][j] & CLS_ROWMASK) * D32;
 #pragma unroll
-      for (int f = 0; f < 4; ++f) xb[P][j][f] = TEMX_XLOAD(fb[f] + off);
+      for (int f = 0; f < NF; ++f) xb[P][j][f] = TEMX_XLOAD(fb[f] + off);
     }
   };
   auto park_north = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int f = 0; f < 4; ++f) { sN[f] = s[f]; x0N[f] = x0[f]; s[f] = 0.0; }
+    for (int f = 0; f < NF; ++f) { sN[f] = s[f]; x0N[f] = x0[f]; s[f] = 0.0; }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { qN[k] = q[k]; q[k] = 0.0; }
+    for (int k = 0; k < NP; ++k) { qN[k] = q[k]; q[k] = 0.0; }
     cntN = cnt;
     cnt = 0.0;
   };
@@ -912,32 +928,32 @@ sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restr
       if (south && north_open) park_north();
       north_open = !south;
 #pragma unroll
-      for (int f = 0; f < 4; ++f) x0[f] = (double)xb[P][0][f];
+      for (int f = 0; f < NF; ++f) x0[f] = (double)xb[P][0][f];
     }
     prev_south = south;
     if (fl & 1) {
 #pragma unroll
       for (int j = 0; j < MB; ++j) {
         const double w = er[P][j] < 0 ? 0.0 : 1.0;
-        double dx[4];
+        double dx[NF];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) dx[f] = (double)xb[P][j][f] - x0[f];
+        for (int f = 0; f < NF; ++f) dx[f] = (double)xb[P][j][f] - x0[f];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) s[f] += w * dx[f];
+        for (int f = 0; f < NF; ++f) s[f] += w * dx[f];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) q[k] += (w * dx[KD::pa(k)]) * dx[KD::pb(k)];
+        for (int k = 0; k < NP; ++k) q[k] += (w * dx[KD::pa(k)]) * dx[KD::pb(k)];
         cnt += w;
       }
     } else {
 #pragma unroll
       for (int j = 0; j < MB; ++j) {
-        double dx[4];
+        double dx[NF];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) dx[f] = (double)xb[P][j][f] - x0[f];
+        for (int f = 0; f < NF; ++f) dx[f] = (double)xb[P][j][f] - x0[f];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) s[f] += dx[f];
+        for (int f = 0; f < NF; ++f) s[f] += dx[f];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) q[k] += dx[KD::pa(k)] * dx[KD::pb(k)];
+        for (int k = 0; k < NP; ++k) q[k] += dx[KD::pa(k)] * dx[KD::pb(k)];
       }
       cnt += (double)MB;
     }
@@ -951,15 +967,15 @@ sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restr
       ++grp;
       load_ys(grp);
       // ---- reference at the class latitudes: E = even part, O = odd part; r_N = E + O, r_S = E - O
-      double E[4], O[4];
+      double E[NF], O[NF];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) E[f] = O[f] = 0.0;
+      for (int f = 0; f < NF; ++f) E[f] = O[f] = 0.0;
 #pragma unroll
       for (int tb = 0; tb < 2 * NBR; ++tb) {
         const int blk = tb < NBR ? tb : TBX + (tb - NBR);
         const double ya = yst[blk * 16 + aoff_r];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
+        for (int f = 0; f < NF; ++f) {
           if (tb < NBR)
             E[f] = TEMX_MFMA4(ya, cb[(f * 2 * NBR + tb) * 64], E[f]);
           else
@@ -967,19 +983,19 @@ sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restr
         }
       }
       // ---- sums of the shifted fields and of their products, per side (theta = T x the column scale)
-      double SN[4], SS[4], PN[3], PS[3], mN[4], mS[4];
+      double SN[NF], SS[NF], PN[NP], PS[NP], mN[NF], mS[NF];
       const double rnN = cntN > 0.0 ? 1.0 / cntN : 0.0, rnS = cnt > 0.0 ? 1.0 / cnt : 0.0;
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        const double sc = f == 2 ? sth : 1.0;
+      for (int f = 0; f < NF; ++f) {
+        const double sc = f == KD::TF ? sth : 1.0;
         mN[f] = (sN[f] * rnN + x0N[f]) * sc - (E[f] + O[f]);     // side mean minus the reference
         mS[f] = (s[f] * rnS + x0[f]) * sc - (E[f] - O[f]);
         SN[f] = cntN * mN[f];
         SS[f] = cnt * mS[f];
       }
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const double sc = k == 2 ? sth : 1.0;
+      for (int k = 0; k < NP; ++k) {
+        const double sc = k == KD::TP ? sth : 1.0;
         PN[k] = (qN[k] - sN[KD::pa(k)] * sN[KD::pb(k)] * rnN) * sc + cntN * mN[KD::pa(k)] * mN[KD::pb(k)];
         PS[k] = (q[k] - s[KD::pa(k)] * s[KD::pb(k)] * rnS) * sc + cnt * mS[KD::pa(k)] * mS[KD::pb(k)];
       }
@@ -987,23 +1003,23 @@ sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restr
       for (int t = 0; t < NBX; ++t) {
         const double ya = yst[t * 16 + aoff_p];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) ax[f][t] = TEMX_MFMA4(ya, t < TBX ? SN[f] + SS[f] : SN[f] - SS[f], ax[f][t]);
+        for (int f = 0; f < NFX; ++f) ax[f][t] = TEMX_MFMA4(ya, t < TBX ? SN[f] + SS[f] : SN[f] - SS[f], ax[f][t]);
         const int tp = t < TBX ? t : t - TBX;                     // the product blocks are the first TBS of each parity
         if (tp < TBS) {
           const int ta = t < TBX ? tp : TBS + tp;
-          double v[3];
+          double v[NP];
 #pragma unroll
-          for (int k = 0; k < 3; ++k) v[k] = apl[(k * 2 * TBS + ta) * 64];
+          for (int k = 0; k < NP; ++k) v[k] = apl[(k * 2 * TBS + ta) * 64];
 #pragma unroll
-          for (int k = 0; k < 3; ++k) v[k] = TEMX_MFMA4(ya, t < TBX ? PN[k] + PS[k] : PN[k] - PS[k], v[k]);
+          for (int k = 0; k < NP; ++k) v[k] = TEMX_MFMA4(ya, t < TBX ? PN[k] + PS[k] : PN[k] - PS[k], v[k]);
 #pragma unroll
-          for (int k = 0; k < 3; ++k) apl[(k * 2 * TBS + ta) * 64] = v[k];
+          for (int k = 0; k < NP; ++k) apl[(k * 2 * TBS + ta) * 64] = v[k];
         }
       }
 #pragma unroll
-      for (int f = 0; f < 4; ++f) s[f] = sN[f] = 0.0;
+      for (int f = 0; f < NF; ++f) s[f] = sN[f] = 0.0;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) q[k] = qN[k] = 0.0;
+      for (int k = 0; k < NP; ++k) q[k] = qN[k] = 0.0;
       cnt = cntN = 0.0;
     }
   };
@@ -1025,18 +1041,18 @@ sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restr
   }
   if (dvalid) {
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < NFX; ++f)
 #pragma unroll
       for (int t = 0; t < NBX; ++t) {
         const int l = symx_harm<TBX>(t, g);
-        if (l < KX) px[(((int64_t)split * 4 + f) * KX + l) * D + d] = ax[f][t];
+        if (l < KX) px[(((int64_t)split * NFX + f) * KX + l) * D + d] = ax[f][t];
       }
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < NP; ++k)
 #pragma unroll
       for (int t = 0; t < 2 * TBS; ++t) {
         const int l = sym_harm<TBS>(t, g);
-        if (l < K) pp[(((int64_t)split * 3 + k) * K + l) * D + d] = apl[(k * 2 * TBS + t) * 64];
+        if (l < K) pp[(((int64_t)split * NP + k) * K + l) * D + d] = apl[(k * 2 * TBS + t) * 64];
       }
   }
 }
@@ -1087,12 +1103,23 @@ __host__ __device__ inline size_t os_contract_lds(int K, int KX, int NQ) {
   return ((size_t)4 * KX + 8 * K + 8 * NQ + 3 * KX + 3 * K) * OSC + big;
 }
 
+// per field: its degree-2L projections [KX][D] and its reference coefficients [KR][D]
+struct OsFields {
+  const double* A[4];
+  const double* rho[4];
+};
+
+// KIND 0: TEM (4 fields, raw sums of all four out, 3 products); KIND 1: tracer (q, v, omega with the projections
+// and references of v and omega taken from the TEM run; raw sums of q out, 2 products)
+template <int KIND>
 __global__ void __launch_bounds__(256)
-os_contract_kernel(const double* __restrict__ Ax, const double* __restrict__ Pp, const double* __restrict__ rho,
+os_contract_kernel(OsFields in, const double* __restrict__ Pp,
                    int K, int KX, int KR, int NQ, int64_t D, const double* __restrict__ Tm,
                    const double* __restrict__ G2inv, const double* __restrict__ G, const double* __restrict__ Gx,
                    const double* __restrict__ Yq, const double* __restrict__ wq2, double* __restrict__ B4,
                    double* __restrict__ B3) {
+  using KD = OsKind<KIND>;
+  constexpr int NF = KD::NF, NP = KD::NP, NOUT = KIND == 0 ? 4 : 1;
   extern __shared__ double sm[];
   const int KK = K * K;
   double* sA = sm;                              // [4][KX][OSC]   projections of the shifted fields
@@ -1108,27 +1135,27 @@ os_contract_kernel(const double* __restrict__ Ax, const double* __restrict__ Pp,
   const int64_t d0 = (int64_t)blockIdx.x * OSC, d = d0 + c;
   const bool dv = d < D;
   const int64_t dc = dv ? d : D - 1;
-  for (int i = r; i < 4 * KX; i += OSR) sA[i * OSC + c] = Ax[(int64_t)i * D + dc];
+  for (int i = r; i < NF * KX; i += OSR) sA[i * OSC + c] = in.A[i / KX][(int64_t)(i % KX) * D + dc];
   os_stage(big, Tm, KK, tid);
   os_stage(big + KK, G2inv, KK, tid);
   __syncthreads();
   const double* sT = big;
   const double* sG2 = big + KK;
-  for (int i = r; i < 4 * K; i += OSR) {        // y = T^T A[:K]
+  for (int i = r; i < NF * K; i += OSR) {       // y = T^T A[:K]
     const int f = i / K, j = i % K;
     double v = 0.0;
     for (int l = 0; l <= j; ++l) v += sT[l * K + j] * sA[(f * KX + l) * OSC + c];
     sW[i * OSC + c] = v;
   }
   __syncthreads();
-  for (int i = r; i < 4 * K; i += OSR) {        // C' = G2inv y
+  for (int i = r; i < NF * K; i += OSR) {       // C' = G2inv y
     const int f = i / K, j = i % K;
     double v = 0.0;
     for (int l = 0; l < K; ++l) v += sG2[j * K + l] * sW[(f * K + l) * OSC + c];
     sAl[i * OSC + c] = v;
   }
   __syncthreads();
-  for (int i = r; i < 4 * K; i += OSR) {        // alpha = T C'
+  for (int i = r; i < NF * K; i += OSR) {       // alpha = T C'
     const int f = i / K, l = i % K;
     double v = 0.0;
     for (int j = l; j < K; ++j) v += sT[l * K + j] * sAl[(f * K + j) * OSC + c];
@@ -1137,14 +1164,14 @@ os_contract_kernel(const double* __restrict__ Ax, const double* __restrict__ Pp,
   __syncthreads();
   for (int i = tid; i < K * KR; i += 256) big[KK + i] = G[(i / KR) * K + (i % KR)];   // G[:, :KR] over G2inv
   __syncthreads();
-  for (int i = r; i < 4 * K; i += OSR) {        // Y-basis sums of the original fields
+  for (int i = r; i < NOUT * K; i += OSR) {     // Y-basis sums of the original fields
     const int f = i / K, l = i % K;
     double v = sA[(f * KX + l) * OSC + c];
-    for (int m = 0; m < KR; ++m) v += big[KK + l * KR + m] * rho[((int64_t)f * KR + m) * D + dc];
+    for (int m = 0; m < KR; ++m) v += big[KK + l * KR + m] * in.rho[f][(int64_t)m * D + dc];
     sAl[i * OSC + c] = v;
   }
   __syncthreads();
-  for (int i = r; i < 4 * K; i += OSR) {        // B4 = T^T (.)
+  for (int i = r; i < NOUT * K; i += OSR) {     // B4 = T^T (.)
     const int f = i / K, j = i % K;
     double v = 0.0;
     for (int l = 0; l <= j; ++l) v += sT[l * K + j] * sAl[(f * K + l) * OSC + c];
@@ -1153,7 +1180,7 @@ os_contract_kernel(const double* __restrict__ Ax, const double* __restrict__ Pp,
   __syncthreads();
   os_stage(big, Yq, NQ * KX, tid);              // Yq[q][k]
   __syncthreads();
-  for (int i = r; i < 4 * NQ; i += OSR) {       // synthesis at the nodes
+  for (int i = r; i < NF * NQ; i += OSR) {      // synthesis at the nodes
     const int f = i / NQ, q = i % NQ;
     const double* yq = big + q * KX;
     double a = 0.0, b = 0.0;
@@ -1163,9 +1190,9 @@ os_contract_kernel(const double* __restrict__ Ax, const double* __restrict__ Pp,
     sAb[i * OSC + c] = b;
   }
   __syncthreads();
-  for (int i = r; i < 3 * KX; i += OSR) {       // cross terms (rows l < K) and c_k, per pair
+  for (int i = r; i < NP * KX; i += OSR) {      // cross terms (rows l < K) and c_k, per pair
     const int p = i / KX, k = i % KX;
-    const int fa = p == 2 ? 1 : 0, fb = p == 0 ? 1 : (p == 1 ? 3 : 2);       // (u, v) (u, omega) (v, theta)
+    const int fa = KD::pa(p), fb = KD::pb(p);
     double x = 0.0, cc = 0.0;
     for (int q = 0; q < NQ; ++q) {
       const double yw = big[q * KX + k] * wq2[q];
@@ -1179,7 +1206,7 @@ os_contract_kernel(const double* __restrict__ Ax, const double* __restrict__ Pp,
   __syncthreads();
   os_stage(big, Gx, K * KX, tid);
   __syncthreads();
-  for (int i = r; i < 3 * K; i += OSR) {        // F = P - cross + Gx c
+  for (int i = r; i < NP * K; i += OSR) {       // F = P - cross + Gx c
     const int p = i / K, l = i % K;
     double t3 = 0.0;
     for (int k = 0; k < KX; ++k) t3 += big[l * KX + k] * sC[(p * KX + k) * OSC + c];
@@ -1188,7 +1215,7 @@ os_contract_kernel(const double* __restrict__ Ax, const double* __restrict__ Pp,
   __syncthreads();
   os_stage(big, Tm, KK, tid);
   __syncthreads();
-  for (int i = r; i < 3 * K; i += OSR) {        // B3 = T^T F
+  for (int i = r; i < NP * K; i += OSR) {       // B3 = T^T F
     const int p = i / K, j = i % K;
     double v = 0.0;
     for (int l = 0; l <= j; ++l) v += big[l * K + j] * sF[(p * K + l) * OSC + c];

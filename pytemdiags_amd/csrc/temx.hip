@@ -129,6 +129,8 @@ struct temx_plan {
   Split sp_cproj4, sp_cproj1, sp_ceddy, sp_cflux;
   // single-sweep form (kernels_op2.hpp, sweep_os_kernel): no class-sum stream; see build_os_tables / tem_run_os
   bool os_built = false, os_on = false;
+  bool os_valid = false;               // Ax / rho / C4 are those of the latest single-sweep temx_tem_run (its v, omega serve the tracer)
+  DevBuf Axq, Ppq, rho_t;              // tracer in the single-sweep form
   int TBX = 0, KX = 0, KR = 0, NQ = 0;
   std::vector<double> h_xc, h_cnt;     // host copies of the class latitudes (cos colat) and member counts
   std::vector<int> h_crow;             // host copy of the row table
@@ -1496,21 +1498,21 @@ static int build_os_tables(temx_plan* pl) {
   return TEMX_OK;
 }
 
-template <typename T>
+template <typename T, int KIND>
 static int launch_sweep_os_t(temx_plan* pl, const FieldPtrs<4>& fp, bool sub, const double* rho, double* partial,
                              const Split& sp, hipStream_t st) {
+  using KD = OsKind<KIND>;
   const int2* cuts = nullptr;
   if (int rc = os_cuts(pl, sub, sp.nsplit, &cuts)) return rc;
   dim3 grid(sp.grid), block(256);
   constexpr int NBR = 2;
-  constexpr int PDv = sizeof(T) == 4 ? 4 : 2;
-  const int64_t KD4 = (int64_t)4 * pl->KX * pl->D;
+  constexpr int PDv = sizeof(T) == 4 ? 4 : 2;       // (a 3-deep ring measured slower for the tracer kind: 8.7 vs 8.4 ms)
   double* px = partial;
-  double* pp = partial + (int64_t)sp.nsplit * KD4;
+  double* pp = partial + (int64_t)sp.nsplit * KD::NFX * pl->KX * pl->D;
 #define TEMX_LOS(TBSv, TBXv)                                                                                        \
   do {                                                                                                              \
-    auto kern = sweep_os_kernel<T, TBSv, TBXv, NBR, PDv>;                                                           \
-    const size_t lds = ((size_t)4 * 2 * TBXv * 16 + (size_t)4 * 4 * 2 * NBR * 64 + (size_t)4 * 3 * 2 * TBSv * 64) * 8; \
+    auto kern = sweep_os_kernel<T, TBSv, TBXv, NBR, PDv, KIND>;                                                     \
+    const size_t lds = ((size_t)4 * 2 * TBXv * 16 + (size_t)4 * KD::NF * 2 * NBR * 64 + (size_t)4 * KD::NP * 2 * TBSv * 64) * 8; \
     static std::atomic<uint64_t> attr_set{0};                                                                       \
     if (int rc_ = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(kern), (int)lds)) return rc_;   \
     hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->D, pl->K, pl->KX, sub ? pl->ycx_s.d() : pl->ycx.d(),     \
@@ -1526,10 +1528,27 @@ static int launch_sweep_os_t(temx_plan* pl, const FieldPtrs<4>& fp, bool sub, co
   return TEMX_OK;
 }
 
+template <int KIND>
+static int launch_sweep_os(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, bool sub, const double* rho, double* partial,
+                           const Split& sp, hipStream_t st) {
+  return dtype == TEMX_F64 ? launch_sweep_os_t<double, KIND>(pl, fp, sub, rho, partial, sp, st)
+                           : launch_sweep_os_t<float, KIND>(pl, fp, sub, rho, partial, sp, st);
+}
+
 static bool os_supported(const temx_plan* pl) {
   if (!pl->cls || pl->large || pl->weighted || !pl->qbasis || pl->h_crow.empty()) return false;
   const int tbx = (pl->L + 1 + 3) / 4;          // blocks of 4 even harmonics up to degree 2L
   return (pl->TBS == 7 && tbx <= 13) || (pl->TBS == 4 && tbx <= 8) || (pl->TBS == 2 && tbx <= 4);
+}
+
+// the single-sweep forms run for fp64 inputs; fp32 inputs keep the class-sum forms (their records are a quarter
+// of the traffic, not an eighth, but the rows are read in 64-byte pieces either way and the heavier sweep
+// measured slower -- ne240 x 128 x 1: 2.5 vs 2.2 ms) unless TEMX_SINGLE_SWEEP=1 forces them
+static bool os_active(const temx_plan* pl, int dtype) {
+  if (!pl->os_on) return false;
+  if (dtype == TEMX_F64) return true;
+  const char* e = getenv("TEMX_SINGLE_SWEEP");
+  return e && e[0] == '1';
 }
 
 static int tem_run_os(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, double* results, double* zonal, void* stream) {
@@ -1537,11 +1556,9 @@ static int tem_run_os(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, double* 
   int rc;
   const int64_t D = pl->D;
   const int64_t KD4 = (int64_t)4 * pl->KX * D, KD3 = (int64_t)3 * pl->K * D;
-  pl->op_valid = pl->c4_valid = pl->tq_valid = false;       // no class sums on this path
+  pl->op_valid = pl->c4_valid = pl->tq_valid = pl->os_valid = false;       // no class sums on this path
   // 1. reference: the same sweep over the subsample with a zero reference, degree < KR fit
-  rc = dtype == TEMX_F64 ? launch_sweep_os_t<double>(pl, fp, true, pl->rho0.d(), pl->partial.d(), pl->sp_os_s, st)
-                         : launch_sweep_os_t<float>(pl, fp, true, pl->rho0.d(), pl->partial.d(), pl->sp_os_s, st);
-  if (rc) return rc;
+  if ((rc = launch_sweep_os<0>(pl, fp, dtype, true, pl->rho0.d(), pl->partial.d(), pl->sp_os_s, st))) return rc;
   if ((rc = launch_reduce(pl, pl->partial.d(), pl->sp_os_s.nsplit, KD4, pl->Axs.d(), st))) return rc;
   hipLaunchKernelGGL(os_ref_solve_kernel, dim3((unsigned)((D + 255) / 256), 4), dim3(256), 0, st, pl->Axs.d(), pl->KX, pl->KR, D,
                      pl->Gsinv.d(), pl->rho.d());
@@ -1549,8 +1566,7 @@ static int tem_run_os(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, double* 
   // 2. the sweep
   TimedLaunch tl{};
   time_begin(pl, 0, st, tl);
-  rc = dtype == TEMX_F64 ? launch_sweep_os_t<double>(pl, fp, false, pl->rho.d(), pl->partial.d(), pl->sp_os, st)
-                         : launch_sweep_os_t<float>(pl, fp, false, pl->rho.d(), pl->partial.d(), pl->sp_os, st);
+  rc = launch_sweep_os<0>(pl, fp, dtype, false, pl->rho.d(), pl->partial.d(), pl->sp_os, st);
   time_end(pl, 0, st, tl);
   if (rc) return rc;
   if ((rc = launch_reduce(pl, pl->partial.d(), pl->sp_os.nsplit, KD4, pl->Ax.d(), st))) return rc;
@@ -1561,9 +1577,14 @@ static int tem_run_os(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, double* 
     time_begin(pl, 1, st, t2);
     const size_t lds = os_contract_lds(pl->K, pl->KX, pl->NQ) * 8;
     static std::atomic<uint64_t> attr_set{0};
-    if ((rc = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(os_contract_kernel), 160 * 1024))) return rc;
-    hipLaunchKernelGGL(os_contract_kernel, dim3((unsigned)((D + OSC - 1) / OSC)), dim3(256), lds, st, pl->Ax.d(), pl->Pp.d(),
-                       pl->rho.d(), pl->K, pl->KX, pl->KR, pl->NQ, D, pl->T.d(), pl->Ginv.d(), pl->G.d(), pl->Gx.d(),
+    if ((rc = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(os_contract_kernel<0>), 160 * 1024))) return rc;
+    OsFields in;
+    for (int f = 0; f < 4; ++f) {
+      in.A[f] = pl->Ax.d() + (int64_t)f * pl->KX * D;
+      in.rho[f] = pl->rho.d() + (int64_t)f * pl->KR * D;
+    }
+    hipLaunchKernelGGL(os_contract_kernel<0>, dim3((unsigned)((D + OSC - 1) / OSC)), dim3(256), lds, st, in, pl->Pp.d(),
+                       pl->K, pl->KX, pl->KR, pl->NQ, D, pl->T.d(), pl->Ginv.d(), pl->G.d(), pl->Gx.d(),
                        pl->gaunt.d(), pl->wq2.d(), pl->B4.d(), pl->B3.d());
     HIPCHK(hipGetLastError());
     time_end(pl, 1, st, t2);
@@ -1571,7 +1592,60 @@ static int tem_run_os(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, double* 
   // 4. as after stage 2: coefficients and zonal means of the four fields, then the epilogue
   if ((rc = launch_solve(pl, pl->B4.d(), 4, D, pl->C4.d(), pl->zb.d(), st))) return rc;
   pl->c4_valid = true;
-  return temx_tem_stage3(pl, pl->B3.d(), results, zonal, stream);
+  if ((rc = temx_tem_stage3(pl, pl->B3.d(), results, zonal, stream))) return rc;
+  pl->os_valid = true;            // Ax, rho describe these fields: the tracer's single sweep may follow
+  return TEMX_OK;
+}
+
+static int tracer_ws(temx_plan* pl);
+
+// Tracer in the single-sweep form: (q, v, omega) read once, no class sums.  The degree-2L projections and the
+// references of v and omega are those the TEM run left in the plan (os_valid): the same v and omega must be
+// handed over.  q gets its own reference from a pre-pass, is projected to degree 2L, q v and q omega to degree L.
+static int tracer_run_os(temx_plan* pl, const void* q, const void* va, const void* wap, int dtype, double* tres,
+                         double* tzon, void* stream) {
+  hipStream_t st = S_(stream);
+  int rc;
+  const int64_t D = pl->D, KXD = (int64_t)pl->KX * D, KD = (int64_t)pl->K * D, KRD = (int64_t)pl->KR * D;
+  if ((rc = tracer_ws(pl))) return rc;
+  if ((rc = pl->Axq.ensure((size_t)2 * KXD * 8))) return rc;          // [0]: main run, [1]: pre-pass
+  if ((rc = pl->Ppq.ensure((size_t)2 * KD * 8))) return rc;
+  if ((rc = pl->rho_t.ensure((size_t)3 * KRD * 8))) return rc;
+  const FieldPtrs<4> fp = four(q, va, wap, nullptr);
+  pl->tq_valid = false;
+  // reference of q from the subsample (the references of v, omega do not matter there: only q's projection is used)
+  if ((rc = launch_sweep_os<1>(pl, fp, dtype, true, pl->rho0.d(), pl->partial.d(), pl->sp_os_s, st))) return rc;
+  if ((rc = launch_reduce(pl, pl->partial.d(), pl->sp_os_s.nsplit, KXD, pl->Axq.d() + KXD, st))) return rc;
+  hipLaunchKernelGGL(os_ref_solve_kernel, dim3((unsigned)((D + 255) / 256), 1), dim3(256), 0, st, pl->Axq.d() + KXD, pl->KX,
+                     pl->KR, D, pl->Gsinv.d(), pl->rho_t.d());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(pl->rho_t.d() + KRD, pl->rho.d() + 1 * KRD, (size_t)KRD * 8, hipMemcpyDeviceToDevice, st));   // v
+  HIPCHK(hipMemcpyAsync(pl->rho_t.d() + 2 * KRD, pl->rho.d() + 3 * KRD, (size_t)KRD * 8, hipMemcpyDeviceToDevice, st));   // omega
+  if ((rc = launch_sweep_os<1>(pl, fp, dtype, false, pl->rho_t.d(), pl->partial.d(), pl->sp_os, st))) return rc;
+  if ((rc = launch_reduce(pl, pl->partial.d(), pl->sp_os.nsplit, KXD, pl->Axq.d(), st))) return rc;
+  if ((rc = launch_reduce(pl, pl->partial.d() + (int64_t)pl->sp_os.nsplit * KXD, pl->sp_os.nsplit, 2 * KD, pl->Ppq.d(), st))) return rc;
+  {
+    const size_t lds = os_contract_lds(pl->K, pl->KX, pl->NQ) * 8;
+    static std::atomic<uint64_t> attr_set{0};
+    if ((rc = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(os_contract_kernel<1>), 160 * 1024))) return rc;
+    OsFields in{};
+    in.A[0] = pl->Axq.d();
+    in.A[1] = pl->Ax.d() + 1 * KXD;
+    in.A[2] = pl->Ax.d() + 3 * KXD;
+    in.rho[0] = pl->rho_t.d();
+    in.rho[1] = pl->rho.d() + 1 * KRD;
+    in.rho[2] = pl->rho.d() + 3 * KRD;
+    hipLaunchKernelGGL(os_contract_kernel<1>, dim3((unsigned)((D + OSC - 1) / OSC)), dim3(256), lds, st, in, pl->Ppq.d(),
+                       pl->K, pl->KX, pl->KR, pl->NQ, D, pl->T.d(), pl->Ginv.d(), pl->G.d(), pl->Gx.d(), pl->gaunt.d(),
+                       pl->wq2.d(), pl->Bq.d(), pl->Bq2.d());
+    HIPCHK(hipGetLastError());
+  }
+  // coefficients Ct = (C_q, C_v, C_w) and qb -> tz[0], as the other tracer stage 2 forms leave them
+  const size_t slab = (size_t)pl->K4 * D * 8;
+  if ((rc = launch_solve(pl, pl->Bq.d(), 1, D, pl->Ct.d(), pl->tz.d(), st))) return rc;
+  HIPCHK(hipMemcpyAsync((char*)pl->Ct.p + slab, (char*)pl->C4.p + slab, slab, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync((char*)pl->Ct.p + 2 * slab, (char*)pl->C4.p + 3 * slab, slab, hipMemcpyDeviceToDevice, st));
+  return temx_tracer_stage3(pl, pl->Bq2.d(), tres, tzon, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1609,7 +1683,7 @@ void temx_plan_destroy(temx_plan* pl) {
   pl->gblk.release();
   pl->ypblk.release();
   for (DevBuf* b : {&pl->T, &pl->Qp, &pl->GinvA, &pl->G2, &pl->xo, &pl->xc, &pl->ycx, &pl->ycx_s, &pl->crow_s, &pl->rho,
-                    &pl->rho0, &pl->gaunt, &pl->wq2, &pl->Gx, &pl->Gsinv, &pl->Ax, &pl->Axs, &pl->Pp})
+                    &pl->rho0, &pl->gaunt, &pl->wq2, &pl->Axq, &pl->Ppq, &pl->rho_t, &pl->Gx, &pl->Gsinv, &pl->Ax, &pl->Axs, &pl->Pp})
     b->release();
   for (auto& kv : pl->csplits_s) kv.second.release();
   for (auto& kv : pl->csplits) kv.second.release();
@@ -2111,7 +2185,7 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
   // (tem_ready fails) until the last allocation has succeeded
   pl->tem = false;
   pl->onepass = pl->lone = pl->op_valid = pl->xb_valid = pl->tq_valid = false;
-  pl->os_on = false;
+  pl->os_on = pl->os_valid = false;
   pl->nlev = nlev;
   pl->nt = nt;
   pl->D = (int64_t)nlev * nt;
@@ -2317,6 +2391,7 @@ int temx_tem_stage1(temx_plan* pl, const void* ua, const void* va, const void* t
   const Split& sp = pl->cls ? pl->sp_cproj4 : (sp4 ? pl->sp_sproj4 : pl->sp_proj4);
   const bool op = pl->cls && pl->onepass;
   pl->op_valid = false;
+  pl->os_valid = false;
   pl->c4_valid = false;          // C4 still describes the previous fields until a stage-2 solve has run
   pl->tq_valid = false;          // tracer class sums pair with the v, omega sums of one TEM run
   rc = op      ? launch_sweep_op<0>(pl, fp, dtype, pl->partial.d(), sp, st)
@@ -2484,12 +2559,7 @@ int temx_tem_run(temx_plan* pl, const void* ua, const void* va, const void* ta, 
                  int dtype, double* results, double* zonal, void* stream) {
   int rc = tem_ready(pl);
   if (rc) return rc;
-  // (fp32 inputs keep the class-sum form: their records are a quarter of the traffic, not an eighth, but the rows
-  //  are read in 64-byte pieces either way and the heavier sweep measured slower -- ne240 x 128 x 1: 2.5 vs 2.2 ms --
-  //  unless TEMX_SINGLE_SWEEP=1 forces it)
-  const char* e_os = pl->os_on && dtype != TEMX_F64 ? getenv("TEMX_SINGLE_SWEEP") : nullptr;
-  const bool os_f32 = e_os && e_os[0] == '1';
-  if (pl->os_on && (dtype == TEMX_F64 || os_f32)) {
+  if (os_active(pl, dtype)) {
     if (!ua || !va || !ta || !wap || !results) return fail(TEMX_EINVAL, "null argument");
     if (dtype != TEMX_F64 && dtype != TEMX_F32) return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
     HIPCHK(hipSetDevice(pl->device));
@@ -2698,7 +2768,7 @@ int temx_tem_tracer_stage1(temx_plan* pl, const void* ua, const void* va, const 
   if ((rc = pl->csq.ensure((size_t)pl->cgroups * sp.ndt * 2 * 64 * 8))) return rc;
   if ((rc = pl->Pq2.ensure((size_t)2 * KD * 8))) return rc;
   if ((rc = pl->partial.ensure(std::max((size_t)sp.nsplit * 10 * KD * 8, pl->partial.bytes)))) return rc;
-  pl->op_valid = pl->c4_valid = pl->tq_valid = false;
+  pl->op_valid = pl->c4_valid = pl->tq_valid = pl->os_valid = false;
   FieldPtrs<5> fp;
   fp.p[0] = ua; fp.p[1] = va; fp.p[2] = ta; fp.p[3] = wap; fp.p[4] = q;
   TimedLaunch tl{};
@@ -2724,7 +2794,8 @@ int temx_tem_tracer_run(temx_plan* pl, const void* ua, const void* va, const voi
   int rc = tem_ready(pl);
   if (rc) return rc;
   if (!q || !tres) return fail(TEMX_EINVAL, "null argument");
-  if (!(pl->cls && pl->onepass) || pl->large) {      // any other path: the two runs one after the other
+  // any other path -- or the single-sweep forms, which beat the fused class-sum sweep -- : the two runs one after the other
+  if (!(pl->cls && pl->onepass) || pl->large || os_active(pl, dtype)) {
     if ((rc = temx_tem_run(pl, ua, va, ta, wap, dtype, results, zonal, stream))) return rc;
     return temx_tracer_run(pl, q, va, wap, dtype, tres, tzon, stream);
   }
@@ -2740,6 +2811,12 @@ int temx_tracer_run(temx_plan* pl, const void* q, const void* va, const void* wa
                     double* tres, double* tzon, void* stream) {
   int rc = tem_ready(pl);
   if (rc) return rc;
+  if (pl->os_valid && pl->c4_valid && os_active(pl, dtype)) {   // after a single-sweep TEM run: the tracer's single sweep
+    if (!q || !va || !wap || !tres) return fail(TEMX_EINVAL, "null argument");
+    if (dtype != TEMX_F64 && dtype != TEMX_F32) return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
+    HIPCHK(hipSetDevice(pl->device));
+    return tracer_run_os(pl, q, va, wap, dtype, tres, tzon, stream);
+  }
   if ((rc = tracer_ws(pl))) return rc;
   // The one-pass form reads (q, v, omega) once instead of q + (q, v, omega), but its sweep shares a SIMD
   // with fewer waves than the two-pass kernels: measured on ne120 x 72 x 30 it is no faster (10.2 ms

@@ -713,12 +713,19 @@ def test_single_sweep_form(monkeypatch, ne, nlev, nt, dtype, L):
         assert fieldnorm_err(zon[i].cpu().numpy(), getattr(ref, n)) <= tol, n
     res2, _ = plan.tem_run(*d)
     assert torch.equal(res, res2)                                   # fixed-order reductions
-    # what follows a TEM run works from its coefficients: native eddies, tracer (two-pass stages here)
+    # what follows a TEM run: native eddies from its coefficients; the tracer in its own single sweep (it reuses
+    # the degree-2L projections and references of v and omega the TEM run left in the plan)
     ed = plan.tem_eddy(*d)
     assert fieldnorm_err(ed["upvp"].cpu().numpy(), ref.upvp) <= tol
-    tres, _ = plan.tracer_run(dq, d[1], d[3])
+    tres, tzon = plan.tracer_run(dq, d[1], d[3], want_zonal=True)
     for k, n in enumerate(_lib.TRACER_RESULT_NAMES):
         assert fieldnorm_err(tres[k].cpu().numpy(), getattr(ref, n)(0)) <= tol, n
+    for k, n in enumerate(_lib.TRACER_ZONAL_NAMES):
+        assert fieldnorm_err(tzon[k].cpu().numpy(), getattr(ref, n)[0]) <= tol, n
+    ted = plan.tracer_eddy(dq, d[1], d[3])
+    assert fieldnorm_err(ted["qpvp"].cpu().numpy(), ref.qpvp[0]) <= tol
+    r4, _, t4, _ = plan.tem_tracer_run(*d, dq)                     # TEM + tracer in one call: the two single sweeps
+    assert torch.equal(r4, res) and torch.equal(t4, tres)
     # the staged entry points keep the class-sum form and agree
     B4 = plan.tem_stage1(*d)
     r3, _ = plan.tem_stage3(plan.tem_stage2_from_sums(B4))

@@ -55,3 +55,14 @@ sw, n = plan.kernel_timing_read(0)
 print("ne%dx%dx%d TEM + one tracer: separate runs %.3f ms, one fused sweep %.3f ms (its sweep %.3f ms = %.2f TB/s of the 5 "
       "fields); one_pass=%s" % (ne, nlev, nt, sep, fus, sw or float("nan"), 5 * 8 * lat.size * nlev * nt / (sw or 1) / 1e9, plan.one_pass), flush=True)
 plan.close()
+
+# the class-sum forms against the single-sweep forms (TEM run, then the tracer run)
+for form, env in (("class-sum forms", "0"), ("single-sweep forms", "1")):
+    os.environ["TEMX_SINGLE_SWEEP"] = env
+    plan = engine.Plan(lat, lat_zm, 50)
+    plan.set_tem(nlev, nt, plev * 100)
+    plan.tem_run(*f)
+    t_tr = timeit(lambda: plan.tracer_run(q, f[1], f[3]))
+    t_all = timeit(lambda: plan.tem_tracer_run(*f, q))
+    print("ne%dx%dx%d %s (single_sweep=%s): tracer_run %.3f ms, tem_tracer_run %.3f ms" % (ne, nlev, nt, form, plan.single_sweep, t_tr, t_all), flush=True)
+    plan.close()
