@@ -1120,6 +1120,7 @@ os_contract_kernel(OsFields in, const double* __restrict__ Pp,
                    double* __restrict__ B3) {
   using KD = OsKind<KIND>;
   constexpr int NF = KD::NF, NP = KD::NP, NOUT = KIND == 0 ? 4 : 1;
+  static_assert(OSC == 4, "a thread owns one output row for the four columns of the workgroup");
   extern __shared__ double sm[];
   const int KK = K * K;
   double* sA = sm;                              // [4][KX][OSC]   projections of the shifted fields
@@ -1131,95 +1132,132 @@ os_contract_kernel(OsFields in, const double* __restrict__ Pp,
   double* sF = sC + 3 * KX * OSC;               // [3][K][OSC]    cross terms, then F
   double* big = sF + 3 * K * OSC;               // T | G2inv, then Yq, then Gx, then T
   const int tid = threadIdx.x;
-  const int c = tid % OSC, r = tid / OSC;
-  const int64_t d0 = (int64_t)blockIdx.x * OSC, d = d0 + c;
-  const bool dv = d < D;
-  const int64_t dc = dv ? d : D - 1;
-  for (int i = r; i < NF * KX; i += OSR) sA[i * OSC + c] = in.A[i / KX][(int64_t)(i % KX) * D + dc];
+  const int64_t d0 = (int64_t)blockIdx.x * OSC;
+  // a matrix row times the OSC columns of a vector block: one scattered LDS read of the matrix element and one
+  // broadcast read of the four column values per term
+  auto dot4 = [&](const double* mrow, int mstride, const double* v, int n, double (&acc)[OSC]) __attribute__((always_inline)) {
+    // (unrolled: the loop is LDS-latency bound with one workgroup per CU; eight terms in flight)
+#pragma unroll 8
+    for (int k = 0; k < n; ++k) {
+      const double m = mrow[(size_t)k * mstride];
+      const double4 x = *reinterpret_cast<const double4*>(v + k * OSC);
+      acc[0] += m * x.x; acc[1] += m * x.y; acc[2] += m * x.z; acc[3] += m * x.w;
+    }
+  };
+  auto put4 = [&](double* dst, const double (&a)[OSC]) __attribute__((always_inline)) {
+    *reinterpret_cast<double4*>(dst) = make_double4(a[0], a[1], a[2], a[3]);
+  };
+  for (int i = tid; i < NF * KX * OSC; i += 256) {
+    const int row = i / OSC, c = i % OSC;
+    const int64_t d = d0 + c < D ? d0 + c : D - 1;
+    sA[i] = in.A[row / KX][(int64_t)(row % KX) * D + d];
+  }
   os_stage(big, Tm, KK, tid);
   os_stage(big + KK, G2inv, KK, tid);
   __syncthreads();
   const double* sT = big;
   const double* sG2 = big + KK;
-  for (int i = r; i < NF * K; i += OSR) {       // y = T^T A[:K]
+  for (int i = tid; i < NF * K; i += 256) {     // y = T^T A[:K]   (row j of T^T = column j of T, rows l <= j)
     const int f = i / K, j = i % K;
-    double v = 0.0;
-    for (int l = 0; l <= j; ++l) v += sT[l * K + j] * sA[(f * KX + l) * OSC + c];
-    sW[i * OSC + c] = v;
+    double a[OSC] = {0.0, 0.0, 0.0, 0.0};
+    dot4(sT + j, K, sA + (size_t)f * KX * OSC, j + 1, a);
+    put4(sW + (size_t)i * OSC, a);
   }
   __syncthreads();
-  for (int i = r; i < NF * K; i += OSR) {       // C' = G2inv y
+  for (int i = tid; i < NF * K; i += 256) {     // C' = G2inv y
     const int f = i / K, j = i % K;
-    double v = 0.0;
-    for (int l = 0; l < K; ++l) v += sG2[j * K + l] * sW[(f * K + l) * OSC + c];
-    sAl[i * OSC + c] = v;
+    double a[OSC] = {0.0, 0.0, 0.0, 0.0};
+    dot4(sG2 + j * K, 1, sW + (size_t)f * K * OSC, K, a);
+    put4(sAl + (size_t)i * OSC, a);
   }
   __syncthreads();
-  for (int i = r; i < NF * K; i += OSR) {       // alpha = T C'
+  for (int i = tid; i < NF * K; i += 256) {     // alpha = T C'   (row l of T: columns j >= l)
     const int f = i / K, l = i % K;
-    double v = 0.0;
-    for (int j = l; j < K; ++j) v += sT[l * K + j] * sAl[(f * K + j) * OSC + c];
-    sW[i * OSC + c] = v;
+    double a[OSC] = {0.0, 0.0, 0.0, 0.0};
+    dot4(sT + l * K + l, 1, sAl + ((size_t)f * K + l) * OSC, K - l, a);
+    put4(sW + (size_t)i * OSC, a);
   }
   __syncthreads();
   for (int i = tid; i < K * KR; i += 256) big[KK + i] = G[(i / KR) * K + (i % KR)];   // G[:, :KR] over G2inv
-  __syncthreads();
-  for (int i = r; i < NOUT * K; i += OSR) {     // Y-basis sums of the original fields
-    const int f = i / K, l = i % K;
-    double v = sA[(f * KX + l) * OSC + c];
-    for (int m = 0; m < KR; ++m) v += big[KK + l * KR + m] * in.rho[f][(int64_t)m * D + dc];
-    sAl[i * OSC + c] = v;
+  for (int i = tid; i < NOUT * KR * OSC; i += 256) {                                  // rho block -> sAt (free until the synthesis)
+    const int row = i / OSC, c = i % OSC;
+    const int64_t d = d0 + c < D ? d0 + c : D - 1;
+    sAt[i] = in.rho[row / KR][(int64_t)(row % KR) * D + d];
   }
   __syncthreads();
-  for (int i = r; i < NOUT * K; i += OSR) {     // B4 = T^T (.)
+  for (int i = tid; i < NOUT * K; i += 256) {   // Y-basis sums of the original fields: A[:K] + G[:, :KR] rho
+    const int f = i / K, l = i % K;
+    double a[OSC];
+#pragma unroll
+    for (int c = 0; c < OSC; ++c) a[c] = sA[((size_t)f * KX + l) * OSC + c];
+    dot4(big + KK + l * KR, 1, sAt + (size_t)f * KR * OSC, KR, a);
+    put4(sAl + (size_t)i * OSC, a);
+  }
+  __syncthreads();
+  for (int i = tid; i < NOUT * K; i += 256) {   // B4 = T^T (.)
     const int f = i / K, j = i % K;
-    double v = 0.0;
-    for (int l = 0; l <= j; ++l) v += sT[l * K + j] * sAl[(f * K + l) * OSC + c];
-    if (dv) B4[((int64_t)f * K + j) * D + d] = v;
+    double a[OSC] = {0.0, 0.0, 0.0, 0.0};
+    dot4(sT + j, K, sAl + (size_t)f * K * OSC, j + 1, a);
+#pragma unroll
+    for (int c = 0; c < OSC; ++c)
+      if (d0 + c < D) B4[((int64_t)f * K + j) * D + d0 + c] = a[c];
   }
   __syncthreads();
   os_stage(big, Yq, NQ * KX, tid);              // Yq[q][k]
   __syncthreads();
-  for (int i = r; i < NF * NQ; i += OSR) {      // synthesis at the nodes
+  for (int i = tid; i < NF * NQ; i += 256) {    // synthesis at the nodes
     const int f = i / NQ, q = i % NQ;
-    const double* yq = big + q * KX;
-    double a = 0.0, b = 0.0;
-    for (int k = 0; k < KX; ++k) a += yq[k] * sA[(f * KX + k) * OSC + c];
-    for (int l = 0; l < K; ++l) b += yq[l] * sW[(f * K + l) * OSC + c];
-    sAt[i * OSC + c] = a;
-    sAb[i * OSC + c] = b;
+    double a[OSC] = {0.0, 0.0, 0.0, 0.0}, b[OSC] = {0.0, 0.0, 0.0, 0.0};
+    dot4(big + q * KX, 1, sA + (size_t)f * KX * OSC, KX, a);
+    dot4(big + q * KX, 1, sW + (size_t)f * K * OSC, K, b);
+    put4(sAt + (size_t)i * OSC, a);
+    put4(sAb + (size_t)i * OSC, b);
   }
   __syncthreads();
-  for (int i = r; i < NP * KX; i += OSR) {      // cross terms (rows l < K) and c_k, per pair
+  for (int i = tid; i < NP * KX; i += 256) {    // cross terms (rows l < K) and c_k, per pair
     const int p = i / KX, k = i % KX;
     const int fa = KD::pa(p), fb = KD::pb(p);
-    double x = 0.0, cc = 0.0;
+    double x[OSC] = {0.0, 0.0, 0.0, 0.0}, cc[OSC] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
     for (int q = 0; q < NQ; ++q) {
       const double yw = big[q * KX + k] * wq2[q];
-      const double aa = sAb[(fa * NQ + q) * OSC + c], bb = sAb[(fb * NQ + q) * OSC + c];
-      cc += yw * aa * bb;
-      if (k < K) x += yw * (bb * sAt[(fa * NQ + q) * OSC + c] + aa * sAt[(fb * NQ + q) * OSC + c]);
+      const double4 aa = *reinterpret_cast<const double4*>(sAb + ((size_t)fa * NQ + q) * OSC);
+      const double4 bb = *reinterpret_cast<const double4*>(sAb + ((size_t)fb * NQ + q) * OSC);
+      cc[0] += yw * aa.x * bb.x; cc[1] += yw * aa.y * bb.y; cc[2] += yw * aa.z * bb.z; cc[3] += yw * aa.w * bb.w;
+      if (k < K) {
+        const double4 ta = *reinterpret_cast<const double4*>(sAt + ((size_t)fa * NQ + q) * OSC);
+        const double4 tb = *reinterpret_cast<const double4*>(sAt + ((size_t)fb * NQ + q) * OSC);
+        x[0] += yw * (bb.x * ta.x + aa.x * tb.x); x[1] += yw * (bb.y * ta.y + aa.y * tb.y);
+        x[2] += yw * (bb.z * ta.z + aa.z * tb.z); x[3] += yw * (bb.w * ta.w + aa.w * tb.w);
+      }
     }
-    sC[i * OSC + c] = cc;
-    if (k < K) sF[(p * K + k) * OSC + c] = x;
+    put4(sC + (size_t)i * OSC, cc);
+    if (k < K) put4(sF + ((size_t)p * K + k) * OSC, x);
   }
   __syncthreads();
   os_stage(big, Gx, K * KX, tid);
   __syncthreads();
-  for (int i = r; i < NP * K; i += OSR) {       // F = P - cross + Gx c
+  for (int i = tid; i < NP * K; i += 256) {     // F = P - cross + Gx c
     const int p = i / K, l = i % K;
-    double t3 = 0.0;
-    for (int k = 0; k < KX; ++k) t3 += big[l * KX + k] * sC[(p * KX + k) * OSC + c];
-    sF[i * OSC + c] = Pp[((int64_t)p * K + l) * D + dc] - sF[i * OSC + c] + t3;
+    double t3[OSC] = {0.0, 0.0, 0.0, 0.0};
+    dot4(big + l * KX, 1, sC + (size_t)p * KX * OSC, KX, t3);
+#pragma unroll
+    for (int c = 0; c < OSC; ++c) {
+      const int64_t d = d0 + c < D ? d0 + c : D - 1;
+      t3[c] = Pp[((int64_t)p * K + l) * D + d] - sF[(size_t)i * OSC + c] + t3[c];
+    }
+    put4(sAl + (size_t)i * OSC, t3);            // (F in sAl: sF is still being read by other threads)
   }
   __syncthreads();
   os_stage(big, Tm, KK, tid);
   __syncthreads();
-  for (int i = r; i < NP * K; i += OSR) {       // B3 = T^T F
+  for (int i = tid; i < NP * K; i += 256) {     // B3 = T^T F
     const int p = i / K, j = i % K;
-    double v = 0.0;
-    for (int l = 0; l <= j; ++l) v += big[l * K + j] * sF[(p * K + l) * OSC + c];
-    if (dv) B3[((int64_t)p * K + j) * D + d] = v;
+    double a[OSC] = {0.0, 0.0, 0.0, 0.0};
+    dot4(big + j, K, sAl + (size_t)p * K * OSC, j + 1, a);
+#pragma unroll
+    for (int c = 0; c < OSC; ++c)
+      if (d0 + c < D) B3[((int64_t)p * K + j) * D + d0 + c] = a[c];
   }
 }
 
