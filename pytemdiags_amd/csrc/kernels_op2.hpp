@@ -827,7 +827,12 @@ template <> struct OsKind<1> {
   __host__ __device__ static constexpr int pb(int k) { return k == 0 ? 1 : 2; }
 };
 
-template <typename T, int TBS, int TBX, int NBR, int PD, int KIND = 0>
+// DEFER: the projection MFMAs of a finished class-group (4 x 26 + 3 x 14 of them, with the read-modify-write of
+// the LDS accumulators) are not issued in one block at the group's end -- 2600 cycles in which the wave,
+// alone on its SIMD, requests nothing from memory -- but in NCH chunks, one per following batch, each right
+// after that batch's loads have been issued.  The finished group's operands wait in registers, its Y blocks
+// in a second LDS buffer.
+template <typename T, int TBS, int TBX, int NBR, int PD, int KIND = 0, int DEFER = 0>
 __global__ void __launch_bounds__(256, 1)
 sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restrict__ ycx,
                 const int4* __restrict__ crow, const int2* __restrict__ csplit,
@@ -857,9 +862,12 @@ sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restr
   int grp = __builtin_amdgcn_readfirstlane(csplit[split].y);
   const uint32_t aoff_p = (uint32_t)(g * 4 + (lane & 3));
   const uint32_t aoff_r = (uint32_t)((lane & 3) * 4 + g);
-  double* yst = lds + wave * YE;
-  double* cb = lds + 4 * YE + wave * (NF * 2 * NBR * 64) + lane;
-  double* apl = lds + 4 * YE + 4 * (NF * 2 * NBR * 64) + wave * (NP * 2 * TBS * 64) + lane;
+  constexpr int NYB = DEFER != 0 ? 2 : 1;          // Y buffers per wave
+  constexpr int NCH = 4;                      // chunks of a deferred projection
+  double* ybase = lds + wave * (NYB * YE);
+  double* yst = ybase;
+  double* cb = lds + 4 * NYB * YE + wave * (NF * 2 * NBR * 64) + lane;
+  double* apl = lds + 4 * NYB * YE + 4 * (NF * 2 * NBR * 64) + wave * (NP * 2 * TBS * 64) + lane;
   const double sth = (KD::TF >= 0 && colscale != nullptr) ? colscale[dcl] : 1.0;
 #pragma unroll
   for (int i = 0; i < NP * 2 * TBS; ++i) apl[i * 64] = 0.0;
@@ -906,6 +914,45 @@ sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restr
       for (int f = 0; f < NF; ++f) xb[P][j][f] = TEMX_XLOAD(fb[f] + off);
     }
   };
+  // operands of the group whose projection is (partly) pending, the Y buffer they go with, chunks done so far
+  double dS[NFX][2], dP[NP][2];
+  const double* yprev = ybase;
+  int left = 0;                               // chunks of it still to run
+#pragma unroll
+  for (int f = 0; f < NFX; ++f) dS[f][0] = dS[f][1] = 0.0;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) dP[k][0] = dP[k][1] = 0.0;
+  // DEFER 1: fields and products deferred; 2: the fields only (8 operands fewer to hold)
+  auto project_blocks = [&](auto t0c, auto t1c, auto whatc, const double* yb, const double (&S)[NFX][2], const double (&P)[NP][2])
+      __attribute__((always_inline)) {
+    constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value, WHAT = decltype(whatc)::value;
+#pragma unroll
+    for (int t = T0; t < T1; ++t) {
+      const double ya = yb[t * 16 + aoff_p];
+      if constexpr (WHAT & 1) {
+#pragma unroll
+        for (int f = 0; f < NFX; ++f) ax[f][t] = TEMX_MFMA4(ya, S[f][t < TBX ? 0 : 1], ax[f][t]);
+      }
+      const int tp = t < TBX ? t : t - TBX;                     // the product blocks are the first TBS of each parity
+      if ((WHAT & 2) && tp < TBS) {
+        const int ta = t < TBX ? tp : TBS + tp;
+        double v[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) v[k] = apl[(k * 2 * TBS + ta) * 64];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) v[k] = TEMX_MFMA4(ya, P[k][t < TBX ? 0 : 1], v[k]);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) apl[(k * 2 * TBS + ta) * 64] = v[k];
+      }
+    }
+  };
+  // chunk c of the pending projection: blocks [c NBX/NCH, (c+1) NBX/NCH).  The chunk a step runs is its position
+  // in the 4-step unrolled loop (static, so ax[][] stays statically indexed); any NCH consecutive steps cover all.
+  auto pending_chunk = [&](auto cc) __attribute__((always_inline)) {
+    constexpr int C = decltype(cc)::value;
+    project_blocks(std::integral_constant<int, C * NBX / NCH>{}, std::integral_constant<int, (C + 1) * NBX / NCH>{},
+                   std::integral_constant<int, DEFER == 2 ? 1 : 3>{}, yprev, dS, dP);
+  };
   auto park_north = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) { sN[f] = s[f]; x0N[f] = x0[f]; s[f] = 0.0; }
@@ -915,12 +962,19 @@ sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restr
     cnt = 0.0;
   };
   int4 rn;
-  auto step = [&](auto pc, int b) __attribute__((always_inline)) {
-    constexpr int P = decltype(pc)::value;
+  auto step = [&](auto posc, int b) __attribute__((always_inline)) {
+    constexpr int POS = decltype(posc)::value % NCH;   // position in the unrolled loop
+    constexpr int P = decltype(posc)::value % PD;      // slot of the load ring
     if (b + (PD - 1) < b1) {
       const int4 r1 = rn;
       rn = crow[(int64_t)(b + PD) * 4 + g];
       issue(std::integral_constant<int, (P + PD - 1) % PD>{}, r1);
+    }
+    if constexpr (DEFER != 0) {
+      if (left > 0) {                         // the loads of the next batch are in flight meanwhile
+        pending_chunk(std::integral_constant<int, POS>{});
+        --left;
+      }
     }
     const int fl = __builtin_amdgcn_readfirstlane(er[P][0]) >> 27;
     const bool south = (fl & (CLS_SOUTH << 1)) != 0;
@@ -959,6 +1013,13 @@ sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restr
     }
     if (fl & (CLS_LAST << 1)) {
       prev_south = false;
+      if constexpr (DEFER != 0) {
+        if (left > 0)                         // (a group shorter than NCH steps: what is left of the previous projection)
+          static_for<NCH>([&](auto cc) __attribute__((always_inline)) {
+            if (((decltype(cc)::value - POS - 1) & (NCH - 1)) < left) pending_chunk(cc);
+          });
+        yst = yst == ybase ? ybase + YE : ybase;
+      }
 #pragma unroll
       for (int j = 0; j < YJ; ++j)
         if (lane + 64 * j < YE) yst[lane + 64 * j] = ys[j];
@@ -1000,21 +1061,22 @@ sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restr
         PS[k] = (q[k] - s[KD::pa(k)] * s[KD::pb(k)] * rnS) * sc + cnt * mS[KD::pa(k)] * mS[KD::pb(k)];
       }
 #pragma unroll
-      for (int t = 0; t < NBX; ++t) {
-        const double ya = yst[t * 16 + aoff_p];
+      for (int f = 0; f < NFX; ++f) {
+        dS[f][0] = SN[f] + SS[f];
+        dS[f][1] = SN[f] - SS[f];
+      }
 #pragma unroll
-        for (int f = 0; f < NFX; ++f) ax[f][t] = TEMX_MFMA4(ya, t < TBX ? SN[f] + SS[f] : SN[f] - SS[f], ax[f][t]);
-        const int tp = t < TBX ? t : t - TBX;                     // the product blocks are the first TBS of each parity
-        if (tp < TBS) {
-          const int ta = t < TBX ? tp : TBS + tp;
-          double v[NP];
-#pragma unroll
-          for (int k = 0; k < NP; ++k) v[k] = apl[(k * 2 * TBS + ta) * 64];
-#pragma unroll
-          for (int k = 0; k < NP; ++k) v[k] = TEMX_MFMA4(ya, t < TBX ? PN[k] + PS[k] : PN[k] - PS[k], v[k]);
-#pragma unroll
-          for (int k = 0; k < NP; ++k) apl[(k * 2 * TBS + ta) * 64] = v[k];
-        }
+      for (int k = 0; k < NP; ++k) {
+        dP[k][0] = PN[k] + PS[k];
+        dP[k][1] = PN[k] - PS[k];
+      }
+      if constexpr (DEFER != 0) {
+        yprev = yst;
+        left = NCH;
+        if constexpr (DEFER == 2)
+          project_blocks(std::integral_constant<int, 0>{}, std::integral_constant<int, NBX>{}, std::integral_constant<int, 2>{}, yst, dS, dP);
+      } else {
+        project_blocks(std::integral_constant<int, 0>{}, std::integral_constant<int, NBX>{}, std::integral_constant<int, 3>{}, yst, dS, dP);
       }
 #pragma unroll
       for (int f = 0; f < NF; ++f) s[f] = sN[f] = 0.0;
@@ -1033,11 +1095,21 @@ sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restr
       rn = crow[(int64_t)(b0 + k + 1) * 4 + g];
       if (k == 0 || b0 + k < b1) issue(kc, r0);
     });
-    for (int b = b0; b < b1; b += PD)
-      static_for<PD>([&](auto kc) __attribute__((always_inline)) {
+    constexpr int UNR = DEFER != 0 ? (PD % 4 == 0 ? PD : PD % 2 == 0 ? 2 * PD : 4 * PD) : PD;   // lcm(PD, NCH)
+    static_assert(UNR % PD == 0 && (DEFER == 0 || UNR % NCH == 0), "unrolled loop covers whole rings and whole chunk rounds");
+    for (int b = b0; b < b1; b += UNR)
+      static_for<UNR>([&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
         if (k == 0 || b + k < b1) step(kc, b + k);
       });
+  }
+  if constexpr (DEFER != 0) {                 // the last group's projection (its chunks in any order)
+    if (left > 0) {
+      const int first = (b1 - b0) & (NCH - 1);          // position the next step would have had
+      static_for<NCH>([&](auto cc) __attribute__((always_inline)) {
+        if (((decltype(cc)::value - first) & (NCH - 1)) < left) pending_chunk(cc);
+      });
+    }
   }
   if (dvalid) {
 #pragma unroll

@@ -1498,6 +1498,9 @@ static int build_os_tables(temx_plan* pl) {
   return TEMX_OK;
 }
 
+#ifndef TEMX_OS_DEFER
+#define TEMX_OS_DEFER 1
+#endif
 template <typename T, int KIND>
 static int launch_sweep_os_t(temx_plan* pl, const FieldPtrs<4>& fp, bool sub, const double* rho, double* partial,
                              const Split& sp, hipStream_t st) {
@@ -1507,12 +1510,13 @@ static int launch_sweep_os_t(temx_plan* pl, const FieldPtrs<4>& fp, bool sub, co
   dim3 grid(sp.grid), block(256);
   constexpr int NBR = 2;
   constexpr int PDv = sizeof(T) == 4 ? 4 : 2;       // (a 3-deep ring measured slower for the tracer kind: 8.7 vs 8.4 ms)
+  constexpr int DF = TEMX_OS_DEFER;                 // projection of a finished class-group spread over the next 4 batches
   double* px = partial;
   double* pp = partial + (int64_t)sp.nsplit * KD::NFX * pl->KX * pl->D;
 #define TEMX_LOS(TBSv, TBXv)                                                                                        \
   do {                                                                                                              \
-    auto kern = sweep_os_kernel<T, TBSv, TBXv, NBR, PDv, KIND>;                                                     \
-    const size_t lds = ((size_t)4 * 2 * TBXv * 16 + (size_t)4 * KD::NF * 2 * NBR * 64 + (size_t)4 * KD::NP * 2 * TBSv * 64) * 8; \
+    auto kern = sweep_os_kernel<T, TBSv, TBXv, NBR, PDv, KIND, DF>;                                                 \
+    const size_t lds = ((size_t)4 * (DF ? 2 : 1) * 2 * TBXv * 16 + (size_t)4 * KD::NF * 2 * NBR * 64 + (size_t)4 * KD::NP * 2 * TBSv * 64) * 8; \
     static std::atomic<uint64_t> attr_set{0};                                                                       \
     if (int rc_ = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(kern), (int)lds)) return rc_;   \
     hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->D, pl->K, pl->KX, sub ? pl->ycx_s.d() : pl->ycx.d(),     \

@@ -280,22 +280,24 @@ int run(int64_t N, int64_t D, int reps, const char* only) {
       CHK(hipMalloc(&px, (size_t)16 * 4 * KX * D * 8));
       CHK(hipMalloc(&pp, (size_t)16 * 3 * K * D * 8));
     }
-    auto add_os = [&](auto nbrc, auto pdc) {
+    auto add_os = [&](auto nbrc, auto pdc, auto dfc) {
       constexpr int NBR = decltype(nbrc)::value, PD = decltype(pdc)::value;
+      constexpr int DF = decltype(dfc)::value;
       Split sp = choose_split(D, cunits, 256, 4, 8);
       int2* cuts = reinterpret_cast<int2*>(to_dev(group_cuts(gb0, sp.nsplit)));
-      const size_t ldsb = ((size_t)4 * 2 * TBX * 16 + (size_t)4 * 4 * 2 * NBR * 64 + (size_t)4 * 3 * 2 * TBS * 64) * 8;
-      auto kern = sweep_os_kernel<T, TBS, TBX, NBR, PD>;
+      const size_t ldsb = ((size_t)4 * (DF ? 2 : 1) * 2 * TBX * 16 + (size_t)4 * 4 * 2 * NBR * 64 + (size_t)4 * 3 * 2 * TBS * 64) * 8;
+      auto kern = sweep_os_kernel<T, TBS, TBX, NBR, PD, 0, DF>;
       CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
       double *ycx_ = ycx, *rho_ = rho, *px_ = px, *pp_ = pp;
       vars.push_back({"os    ONE sweep, no class-sum stream: 4 x 26 + 3 x 14 accumulators, reference blocks " + std::to_string(NBR) +
-                      ", PD=" + std::to_string(PD), 0, [=](double*) {
+                      ", PD=" + std::to_string(PD) + (DF ? ", deferred projection " + std::to_string(DF) : std::string()), 0, [=](double*) {
         hipLaunchKernelGGL(kern, dim3(sp.grid), dim3(256), ldsb, 0, fp, D, K, KX, ycx_, reinterpret_cast<const int4*>(d_crow), cuts,
                            d_cs, rho_, K4r, px_, pp_, sp.nsplit, sp.ndt); }});
     };
-    add_os(std::integral_constant<int, 2>{}, std::integral_constant<int, sizeof(T) == 8 ? 2 : 4>{});
-    add_os(std::integral_constant<int, 2>{}, std::integral_constant<int, sizeof(T) == 8 ? 3 : 6>{});
-    add_os(std::integral_constant<int, 3>{}, std::integral_constant<int, sizeof(T) == 8 ? 3 : 6>{});
+    using N0 = std::integral_constant<int, 0>; using N1 = std::integral_constant<int, 1>;
+    add_os(std::integral_constant<int, 2>{}, std::integral_constant<int, sizeof(T) == 8 ? 2 : 4>{}, N0{});
+    add_os(std::integral_constant<int, 2>{}, std::integral_constant<int, sizeof(T) == 8 ? 2 : 4>{}, N1{});
+    add_os(std::integral_constant<int, 2>{}, std::integral_constant<int, sizeof(T) == 8 ? 2 : 4>{}, std::integral_constant<int, 2>{});
   }
 #endif
 #ifdef LAB_FUSED
