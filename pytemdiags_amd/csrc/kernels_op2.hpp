@@ -827,6 +827,9 @@ template <> struct OsKind<1> {
   __host__ __device__ static constexpr int pb(int k) { return k == 0 ? 1 : 2; }
 };
 
+#ifndef TEMX_OS_SKIP
+#define TEMX_OS_SKIP 0      // lab builds leave parts of the work out (tools/sweep_lab.hip)
+#endif
 // DEFER: the projection MFMAs of a finished class-group (4 x 26 + 3 x 14 of them, with the read-modify-write of
 // the LDS accumulators) are not issued in one block at the group's end -- 2600 cycles in which the wave,
 // alone on its SIMD, requests nothing from memory -- but in NCH chunks, one per following batch, each right
@@ -972,7 +975,7 @@ sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restr
     }
     if constexpr (DEFER != 0) {
       if (left > 0) {                         // the loads of the next batch are in flight meanwhile
-        pending_chunk(std::integral_constant<int, POS>{});
+        if (!(TEMX_OS_SKIP & 1)) pending_chunk(std::integral_constant<int, POS>{});
         --left;
       }
     }
@@ -985,7 +988,12 @@ sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restr
       for (int f = 0; f < NF; ++f) x0[f] = (double)xb[P][0][f];
     }
     prev_south = south;
-    if (fl & 1) {
+    if (TEMX_OS_SKIP & 4) {                   // (lab: no accumulation; the loads stay live)
+#pragma unroll
+      for (int j = 0; j < MB; ++j)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) asm volatile("" ::"v"(xb[P][j][f]));
+    } else if (fl & 1) {
 #pragma unroll
       for (int j = 0; j < MB; ++j) {
         const double w = er[P][j] < 0 ? 0.0 : 1.0;
@@ -1032,7 +1040,7 @@ sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restr
 #pragma unroll
       for (int f = 0; f < NF; ++f) E[f] = O[f] = 0.0;
 #pragma unroll
-      for (int tb = 0; tb < 2 * NBR; ++tb) {
+      for (int tb = 0; tb < ((TEMX_OS_SKIP & 2) ? 0 : 2 * NBR); ++tb) {
         const int blk = tb < NBR ? tb : TBX + (tb - NBR);
         const double ya = yst[blk * 16 + aoff_r];
 #pragma unroll
@@ -1110,6 +1118,359 @@ sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restr
         if (((decltype(cc)::value - first) & (NCH - 1)) < left) pending_chunk(cc);
       });
     }
+  }
+  if (dvalid) {
+#pragma unroll
+    for (int f = 0; f < NFX; ++f)
+#pragma unroll
+      for (int t = 0; t < NBX; ++t) {
+        const int l = symx_harm<TBX>(t, g);
+        if (l < KX) px[(((int64_t)split * NFX + f) * KX + l) * D + d] = ax[f][t];
+      }
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+#pragma unroll
+      for (int t = 0; t < 2 * TBS; ++t) {
+        const int l = sym_harm<TBS>(t, g);
+        if (l < K) pp[(((int64_t)split * NP + k) * K + l) * D + d] = apl[(k * 2 * TBS + t) * 64];
+      }
+  }
+}
+
+// Loads of the row-map sweeps: wave-uniform row address (SGPR pair) + one 32-bit lane offset, issued by hand.
+// Written as ordinary loads the compiler (ROCm 7.2) either folds the lane offset into per-lane pointers -- one
+// VALU add per load whose result registers it takes from the batch still in flight, so the issue waits for that
+// batch -- or mixes both forms under SGPR pressure.  Issued by hand the loads are invisible to its wait-count
+// pass: row_wait<N>() is the s_waitcnt that makes the named values usable (N = loads issued after them).
+template <typename T> struct RowLoad;
+template <> struct RowLoad<double> {
+  static __device__ __forceinline__ void ld(double& dst, uint32_t voff, uint64_t sbase) {
+    asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+  }
+};
+template <> struct RowLoad<float> {
+  static __device__ __forceinline__ void ld(float& dst, uint32_t voff, uint64_t sbase) {
+    asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+  }
+};
+template <int N, typename T>
+__device__ __forceinline__ void row_wait(T& a, T& b, T& c, T& d) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+template <int N, typename T>
+__device__ __forceinline__ void row_wait(T& a, T& b, T& c) {
+  asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
+}
+template <typename T>
+__device__ __forceinline__ void row_touch(T& a) {      // orders the uses of a behind the waits executed so far
+  asm volatile("" : "+v"(a)::"memory");
+}
+
+// ------------------------------------------------------------------------------------------------
+// The single sweep with row-contiguous loads.  tools/ubench_gather.hip: the same bytes, rows and ring depth read
+// at 5.5 TB/s when one load instruction takes 4 rows x 16 columns (the MFMA B tile, as every other sweep here
+// loads) and at 6.3 TB/s when it takes 1 row x 64 columns (fp32: 3.1 vs 5.1 TB/s; 512-byte rows: 3.2 vs 6.1).
+// The class sums are lane-wise sums over the rows of a class, so the lane map of the loads is free:
+//   * while it reads, wave w of the workgroup owns class slot w of every class-group and all 64 columns of the
+//     workgroup (lane = column): every load is one row x 64 columns with a wave-uniform row address;
+//   * at the end of a class-group the side means and central co-moments of (class, column) cross through LDS
+//     (two workgroup barriers that leave the global loads in flight), and wave w becomes the owner of d-tile w
+//     (lane = class slot x column, the MFMA B layout) for the reference, the shifted sums and the projection,
+//     which is deferred over the next four batches as in sweep_os_kernel<DEFER = 1>.
+// The Y blocks of a group are the same for the four waves: one shared copy, double buffered.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int TBS, int TBX, int NBR, int PD, int KIND = 0>
+__global__ void __launch_bounds__(256, 1)
+sweep_osr_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restrict__ ycx,
+                 const int4* __restrict__ crow, const int2* __restrict__ csplit,
+                 const double* __restrict__ colscale, const double* __restrict__ rho, int K4,
+                 double* __restrict__ px, double* __restrict__ pp, int nsplit, int ndt) {
+  using KD = OsKind<KIND>;
+  constexpr int NF = KD::NF, NFX = KD::NFX, NP = KD::NP;
+  constexpr int NBX = 2 * TBX;
+  constexpr int YE = NBX * 16;
+  constexpr int YJ = (YE + 255) / 256;        // Y elements per thread of the workgroup
+  constexpr int MB = CLS_MB;
+  constexpr int NCH = 4;
+  constexpr int NV = 2 * (NF + NP);           // exchanged per (class, column): side means, central co-moments
+  static_assert(NBR <= TBS && TBS <= TBX, "reference degree <= L <= 2L");
+  static_assert(YJ <= 2, "Y quarter per thread");
+  static_assert((PD - 1) * CLS_MB * KD::NF + (CLS_MB - 1) * KD::NF + 2 <= 63, "the ring is counted in vmcnt (6 bits)");
+  // [2][YE] Y blocks | [16] member counts | [4 waves][NF][2 NBR][64] reference operands |
+  // [4 waves][NP][2 TBS][64] product accumulators | [NV][4 classes][64 columns] exchange
+  extern __shared__ double lds[];
+  int split, dq;
+  if (!wg_work((ndt + 3) / 4, nsplit, split, dq)) return;
+  const int tid = threadIdx.x;
+  const int wave = uniform_wave(), lane = tid & 63;
+  const int c = lane & 15, g = lane >> 4;
+  // reading role: class slot `wave`, column dq * 64 + lane
+  const int64_t colr = (int64_t)dq * 64 + lane < D ? (int64_t)dq * 64 + lane : D - 1;
+  const uint32_t colb32 = (uint32_t)colr * (uint32_t)sizeof(T);   // byte offset of my column in a row
+  // tile role: d-tile dq * 4 + wave, lane = (class slot g, column c)
+  const int dt = dq * 4 + wave;
+  const int64_t d = (int64_t)dt * 16 + c;
+  const bool dvalid = dt < ndt && d < D;
+  const int64_t dcl = dvalid ? d : D - 1;
+  const int b0 = __builtin_amdgcn_readfirstlane(csplit[split].x);
+  const int b1 = __builtin_amdgcn_readfirstlane(csplit[split + 1].x);
+  int grp = __builtin_amdgcn_readfirstlane(csplit[split].y);
+  const uint32_t aoff_p = (uint32_t)(g * 4 + (lane & 3));
+  const uint32_t aoff_r = (uint32_t)((lane & 3) * 4 + g);
+  double* ybase = lds;
+  double* cn = lds + 2 * YE;
+  double* cb = lds + 2 * YE + 16 + wave * (NF * 2 * NBR * 64) + lane;
+  double* apl = lds + 2 * YE + 16 + 4 * (NF * 2 * NBR * 64) + wave * (NP * 2 * TBS * 64) + lane;
+  double* ex = lds + 2 * YE + 16 + 4 * (NF * 2 * NBR * 64) + 4 * (NP * 2 * TBS * 64);
+  double* exw = ex + wave * 64 + lane;                   // [v][my class][my column]
+  const double* exr = ex + g * 64 + wave * 16 + c;       // [v][class g][column of my d-tile]
+  const double sth = (KD::TF >= 0 && colscale != nullptr) ? colscale[colr] : 1.0;
+#pragma unroll
+  for (int i = 0; i < NP * 2 * TBS; ++i) apl[i * 64] = 0.0;
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+#pragma unroll
+    for (int tb = 0; tb < 2 * NBR; ++tb) {
+      const int l = tb < NBR ? 2 * (4 * tb + g) : 2 * (4 * (tb - NBR) + g) + 1;
+      const double v = rho[((int64_t)f * K4 + (l < K ? l : K - 1)) * D + dcl];
+      cb[(f * 2 * NBR + tb) * 64] = l < K ? v : 0.0;
+    }
+  uint64_t fbase[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) fbase[f] = reinterpret_cast<uint64_t>(fp.p[f]);
+
+  double ax[NFX][NBX];
+#pragma unroll
+  for (int f = 0; f < NFX; ++f)
+#pragma unroll
+    for (int t = 0; t < NBX; ++t) ax[f][t] = 0.0;
+  double s[NF], q[NP], x0[NF], cnt = 0.0;
+  double sN[NF], qN[NP], x0N[NF], cntN = 0.0;
+#pragma unroll
+  for (int f = 0; f < NF; ++f) s[f] = x0[f] = sN[f] = x0N[f] = 0.0;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) q[k] = qN[k] = 0.0;
+  bool north_open = false, prev_south = false;
+  const uint32_t D32 = (uint32_t)D;
+
+  T xb[PD][MB][NF];
+  int er[PD][MB];                             // wave-uniform: the rows of this wave's class slot
+  double ys[YJ];
+  const uint32_t yoff32[2] = {(uint32_t)(tid < YE ? tid : 0) * 8u, (uint32_t)(tid + 256 < YE ? tid + 256 : 0) * 8u};
+  auto load_ys = [&](int gi) __attribute__((always_inline)) {   // (by hand as well: a compiler-tracked load would be
+#pragma unroll                                                  // waited for with vmcnt(0), draining the ring once per group)
+    for (int j = 0; j < YJ; ++j) RowLoad<double>::ld(ys[j], yoff32[j], reinterpret_cast<uint64_t>(ycx) + (uint64_t)gi * (YE * 8));
+  };
+  auto issue = [&](auto pc, const int4 rv) __attribute__((always_inline)) {
+    constexpr int P = decltype(pc)::value;
+    er[P][0] = rv.x; er[P][1] = rv.y; er[P][2] = rv.z; er[P][3] = rv.w;
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+      const uint64_t off = (uint64_t)(uint32_t)(er[P][j] & CLS_ROWMASK) * D32 * sizeof(T);   // wave-uniform
+#pragma unroll
+      for (int f = 0; f < NF; ++f) RowLoad<T>::ld(xb[P][j][f], colb32, fbase[f] + off);
+    }
+  };
+  double dS[NFX][2], dP[NP][2];
+  const double* yprev = ybase;
+  int ycur = 0;
+  int left = 0;
+#pragma unroll
+  for (int f = 0; f < NFX; ++f) dS[f][0] = dS[f][1] = 0.0;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) dP[k][0] = dP[k][1] = 0.0;
+  auto pending_chunk = [&](auto cc) __attribute__((always_inline)) {
+    constexpr int C = decltype(cc)::value;
+#pragma unroll
+    for (int t = C * NBX / NCH; t < (C + 1) * NBX / NCH; ++t) {
+      const double ya = yprev[t * 16 + aoff_p];
+#pragma unroll
+      for (int f = 0; f < NFX; ++f) ax[f][t] = TEMX_MFMA4(ya, dS[f][t < TBX ? 0 : 1], ax[f][t]);
+      const int tp = t < TBX ? t : t - TBX;
+      if (tp < TBS) {
+        const int ta = t < TBX ? tp : TBS + tp;
+        double v[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) v[k] = apl[(k * 2 * TBS + ta) * 64];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) v[k] = TEMX_MFMA4(ya, dP[k][t < TBX ? 0 : 1], v[k]);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) apl[(k * 2 * TBS + ta) * 64] = v[k];
+      }
+    }
+  };
+  auto park_north = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) { sN[f] = s[f]; x0N[f] = x0[f]; s[f] = 0.0; }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) { qN[k] = q[k]; q[k] = 0.0; }
+    cntN = cnt;
+    cnt = 0.0;
+  };
+  int4 rn;
+  auto step = [&](auto posc, int b) __attribute__((always_inline)) {
+    constexpr int POS = decltype(posc)::value % NCH;
+    constexpr int P = decltype(posc)::value % PD;
+    {                                         // (past b1: the next cut's rows or the table's padding, never used)
+      const int4 r1 = rn;
+      rn = crow[(int64_t)(b + PD) * 4 + wave];
+      issue(std::integral_constant<int, (P + PD - 1) % PD>{}, r1);
+    }
+    if (left > 0) {                           // the loads of the next batch are in flight meanwhile
+      pending_chunk(std::integral_constant<int, POS>{});
+      --left;
+    }
+    // PD - 1 batches were issued after this one; its rows become usable one by one
+    static_assert(NF == 4 || NF == 3, "row_wait has forms for 3 and 4 fields");
+    static_for<MB>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      constexpr int NW = (PD - 1) * MB * NF + (MB - 1 - j) * NF;
+      if constexpr (NF == 4) row_wait<NW>(xb[P][j][0], xb[P][j][1], xb[P][j][2], xb[P][j][3]);
+      else row_wait<NW>(xb[P][j][0], xb[P][j][1], xb[P][j][2]);
+    });
+#pragma unroll
+    for (int j = 0; j < YJ; ++j) row_touch(ys[j]);   // (issued at least one step ago, in order before this batch)
+    const int fl = er[P][0] >> 27;            // (flags are those of the batch: the same in its four class slots)
+    const bool south = (fl & (CLS_SOUTH << 1)) != 0;
+    if ((fl & (CLS_FIRST << 1)) || (south && !prev_south)) {
+      if (south && north_open) park_north();
+      north_open = !south;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) x0[f] = (double)xb[P][0][f];
+    }
+    prev_south = south;
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+      const double w = er[P][j] < 0 ? 0.0 : 1.0;   // (a padding entry: the whole row of this wave)
+      double dx[NF];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) dx[f] = (double)xb[P][j][f] - x0[f];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) s[f] += w * dx[f];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) q[k] += (w * dx[KD::pa(k)]) * dx[KD::pb(k)];
+      cnt += w;
+    }
+    if (fl & (CLS_LAST << 1)) {
+      prev_south = false;
+      if (north_open) park_north();           // the group has no southern batch: the open side is the northern one
+      north_open = false;
+      if (left > 0)                           // (a group shorter than NCH steps: what is left of the previous projection)
+        static_for<NCH>([&](auto cc) __attribute__((always_inline)) {
+          if (((decltype(cc)::value - POS - 1) & (NCH - 1)) < left) pending_chunk(cc);
+        });
+      // ---- reading role: side means (theta = T x the column scale) and central co-moments of my class
+      const double rnN = cntN > 0.0 ? 1.0 / cntN : 0.0, rnS = cnt > 0.0 ? 1.0 / cnt : 0.0;
+      double val[NV];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const double sc = f == KD::TF ? sth : 1.0;
+        val[f] = (sN[f] * rnN + x0N[f]) * sc;
+        val[NF + NP + f] = (s[f] * rnS + x0[f]) * sc;
+      }
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const double sc = k == KD::TP ? sth : 1.0;
+        val[NF + k] = (qN[k] - sN[KD::pa(k)] * sN[KD::pb(k)] * rnN) * sc;
+        val[2 * NF + NP + k] = (q[k] - s[KD::pa(k)] * s[KD::pb(k)] * rnS) * sc;
+      }
+      // every wave is done with the exchange area of the previous group (LDS reads retired, loads stay in flight)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      ycur ^= 1;
+      double* yw = ybase + ycur * YE;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) exw[v * 256] = val[v];
+      if (lane == 0) {
+        cn[wave] = cntN;
+        cn[4 + wave] = cnt;
+      }
+#pragma unroll
+      for (int j = 0; j < YJ; ++j)
+        if (tid + 256 * j < YE) yw[tid + 256 * j] = ys[j];
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      ++grp;
+      load_ys(grp);
+      // ---- tile role: class slot g, column c of d-tile `wave`
+      double m2[2][NF], c2[2][NP];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        m2[0][f] = exr[f * 256];
+        m2[1][f] = exr[(NF + NP + f) * 256];
+      }
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        c2[0][k] = exr[(NF + k) * 256];
+        c2[1][k] = exr[(2 * NF + NP + k) * 256];
+      }
+      const double nN = cn[g], nS = cn[4 + g];
+      // reference at the class latitudes: E = even part, O = odd part; r_N = E + O, r_S = E - O
+      double E[NF], O[NF];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) E[f] = O[f] = 0.0;
+#pragma unroll
+      for (int tb = 0; tb < 2 * NBR; ++tb) {
+        const int blk = tb < NBR ? tb : TBX + (tb - NBR);
+        const double ya = yw[blk * 16 + aoff_r];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          if (tb < NBR)
+            E[f] = TEMX_MFMA4(ya, cb[(f * 2 * NBR + tb) * 64], E[f]);
+          else
+            O[f] = TEMX_MFMA4(ya, cb[(f * 2 * NBR + tb) * 64], O[f]);
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        m2[0][f] -= E[f] + O[f];              // side mean minus the reference
+        m2[1][f] -= E[f] - O[f];
+      }
+#pragma unroll
+      for (int f = 0; f < NFX; ++f) {
+        const double SNf = nN * m2[0][f], SSf = nS * m2[1][f];
+        dS[f][0] = SNf + SSf;
+        dS[f][1] = SNf - SSf;
+      }
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const double PNk = c2[0][k] + nN * m2[0][KD::pa(k)] * m2[0][KD::pb(k)];
+        const double PSk = c2[1][k] + nS * m2[1][KD::pa(k)] * m2[1][KD::pb(k)];
+        dP[k][0] = PNk + PSk;
+        dP[k][1] = PNk - PSk;
+      }
+      yprev = yw;
+      left = NCH;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) s[f] = sN[f] = 0.0;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) q[k] = qN[k] = 0.0;
+      cnt = cntN = 0.0;
+    }
+  };
+
+  if (b0 < b1) {
+    load_ys(grp);
+    rn = crow[(int64_t)b0 * 4 + wave];
+    static_for<PD - 1>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int k = decltype(kc)::value;
+      const int4 r0 = rn;
+      rn = crow[(int64_t)(b0 + k + 1) * 4 + wave];
+      issue(kc, r0);
+    });
+    constexpr int UNR = PD % 4 == 0 ? PD : PD % 2 == 0 ? 2 * PD : 4 * PD;   // lcm(PD, NCH)
+    for (int b = b0; b < b1; b += UNR)
+      static_for<UNR>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        if (k == 0 || b + k < b1) step(kc, b + k);
+      });
+    // the batches issued past b1 and the last Y prefetch are still landing in registers the compiler believes
+    // free from here on: drain them before anything else is written there
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (left > 0) {
+    const int first = (b1 - b0) & (NCH - 1);
+    static_for<NCH>([&](auto cc) __attribute__((always_inline)) {
+      if (((decltype(cc)::value - first) & (NCH - 1)) < left) pending_chunk(cc);
+    });
   }
   if (dvalid) {
 #pragma unroll

@@ -1511,17 +1511,32 @@ static int launch_sweep_os_t(temx_plan* pl, const FieldPtrs<4>& fp, bool sub, co
   constexpr int NBR = 2;
   constexpr int PDv = sizeof(T) == 4 ? 4 : 2;       // (a 3-deep ring measured slower for the tracer kind: 8.7 vs 8.4 ms)
   constexpr int DF = TEMX_OS_DEFER;                 // projection of a finished class-group spread over the next 4 batches
+  // loads of 1 row x 64 columns (sweep_osr_kernel, the default) or of 4 rows x 16 columns (TEMX_OS_MAP=tile, A/B)
+  const char* em = getenv("TEMX_OS_MAP");
+  const bool tile_map = em && !strcmp(em, "tile");
   double* px = partial;
   double* pp = partial + (int64_t)sp.nsplit * KD::NFX * pl->KX * pl->D;
 #define TEMX_LOS(TBSv, TBXv)                                                                                        \
   do {                                                                                                              \
-    auto kern = sweep_os_kernel<T, TBSv, TBXv, NBR, PDv, KIND, DF>;                                                 \
-    const size_t lds = ((size_t)4 * (DF ? 2 : 1) * 2 * TBXv * 16 + (size_t)4 * KD::NF * 2 * NBR * 64 + (size_t)4 * KD::NP * 2 * TBSv * 64) * 8; \
-    static std::atomic<uint64_t> attr_set{0};                                                                       \
-    if (int rc_ = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(kern), (int)lds)) return rc_;   \
-    hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->D, pl->K, pl->KX, sub ? pl->ycx_s.d() : pl->ycx.d(),     \
-                       static_cast<const int4*>(sub ? pl->crow_s.p : pl->crow.p), cuts, pl->colscale.d(), rho,      \
-                       pl->KR, px, pp, sp.nsplit, sp.ndt);                                                          \
+    if (tile_map) {                                                                                                 \
+      auto kern = sweep_os_kernel<T, TBSv, TBXv, NBR, PDv, KIND, DF>;                                               \
+      const size_t lds = ((size_t)4 * (DF ? 2 : 1) * 2 * TBXv * 16 + (size_t)4 * KD::NF * 2 * NBR * 64 +            \
+                          (size_t)4 * KD::NP * 2 * TBSv * 64) * 8;                                                  \
+      static std::atomic<uint64_t> attr_set{0};                                                                     \
+      if (int rc_ = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(kern), (int)lds)) return rc_; \
+      hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->D, pl->K, pl->KX, sub ? pl->ycx_s.d() : pl->ycx.d(),   \
+                         static_cast<const int4*>(sub ? pl->crow_s.p : pl->crow.p), cuts, pl->colscale.d(), rho,    \
+                         pl->KR, px, pp, sp.nsplit, sp.ndt);                                                        \
+    } else {                                                                                                        \
+      auto kern = sweep_osr_kernel<T, TBSv, TBXv, NBR, 2, KIND>;                                                    \
+      const size_t lds = ((size_t)2 * 2 * TBXv * 16 + 16 + (size_t)4 * KD::NF * 2 * NBR * 64 +                      \
+                          (size_t)4 * KD::NP * 2 * TBSv * 64 + (size_t)2 * (KD::NF + KD::NP) * 256) * 8;            \
+      static std::atomic<uint64_t> attr_set{0};                                                                     \
+      if (int rc_ = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(kern), (int)lds)) return rc_; \
+      hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->D, pl->K, pl->KX, sub ? pl->ycx_s.d() : pl->ycx.d(),   \
+                         static_cast<const int4*>(sub ? pl->crow_s.p : pl->crow.p), cuts, pl->colscale.d(), rho,    \
+                         pl->KR, px, pp, sp.nsplit, sp.ndt);                                                        \
+    }                                                                                                               \
   } while (0)
   if (pl->TBS == 7 && pl->TBX == 13) TEMX_LOS(7, 13);
   else if (pl->TBS == 4 && pl->TBX == 8) TEMX_LOS(4, 8);
@@ -1865,6 +1880,15 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
       pl->h_xc = ct.xc;
       pl->h_cnt = ct.cnt;
       pl->h_crow = ct.crow;
+      if (const char* dp = getenv("TEMX_DUMP_CROW")) {     // development: the row table as tools/sweep_lab.hip reads it (LAB_CROW)
+        if (FILE* fh = fopen(dp, "wb")) {
+          const int32_t hdr[2] = {(int32_t)ct.ngroups, (int32_t)ct.crow.size()};
+          fwrite(hdr, 4, 2, fh);
+          fwrite(ct.gbatch0.data(), 4, (size_t)ct.ngroups + 1, fh);
+          fwrite(ct.crow.data(), 4, ct.crow.size(), fh);
+          fclose(fh);
+        }
+      }
       pl->cls_npad = (ct.ngroups + 1) * 4;
       pl->gbatch0 = std::move(ct.gbatch0);
       pl->cgroups = ct.ngroups;

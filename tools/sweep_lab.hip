@@ -205,12 +205,26 @@ int run(int64_t N, int64_t D, int reps, const char* only) {
     std::sort(c.n.begin(), c.n.end()); std::sort(c.s.begin(), c.s.end());
     cls.push_back(c);
   }
-  const int64_t ng = ((int64_t)cls.size() + 3) / 4;
+  int64_t ng = ((int64_t)cls.size() + 3) / 4;
+  std::vector<int> crow_file, gb0_file;
+  if (const char* cf = getenv("LAB_CROW")) {        // the library's own row table (TEMX_DUMP_CROW): ngroups, entries, gbatch0, crow
+    FILE* fh = fopen(cf, "rb");
+    if (!fh) { printf("cannot open %s\n", cf); return 1; }
+    int32_t hdr[2];
+    if (fread(hdr, 4, 2, fh) != 2) return 1;
+    gb0_file.resize((size_t)hdr[0] + 1); crow_file.resize((size_t)hdr[1]);
+    if (fread(gb0_file.data(), 4, gb0_file.size(), fh) != gb0_file.size()) return 1;
+    if (fread(crow_file.data(), 4, crow_file.size(), fh) != crow_file.size()) return 1;
+    fclose(fh);
+    ng = hdr[0];
+    printf("row table from %s: %d class-groups, %d batches\n", cf, hdr[0], gb0_file.back());
+  }
 #ifdef TEMX_LAB
   CHK(hipMemcpyToSymbol(HIP_SYMBOL(temx_lab_ngr), &ng, sizeof(ng)));
 #endif
   std::vector<int> crow, gb0, crow16_2, gb16_2, crow16_4, gb16_4;
   build_crow(cls, crow, gb0);
+  if (!crow_file.empty()) { crow = crow_file; gb0 = gb0_file; }
   build_crow16(cls, 2, crow16_2, gb16_2);
   build_crow16(cls, 4, crow16_4, gb16_4);
   int* d_crow = to_dev(crow); int* d_crow16_2 = to_dev(crow16_2); int* d_crow16_4 = to_dev(crow16_4);
@@ -232,6 +246,10 @@ int run(int64_t N, int64_t D, int reps, const char* only) {
     hipLaunchKernelGGL(fill_kernel<T>, dim3(4096), dim3(256), 0, 0, p, N * D, 1234u + f, base[f], amp[f]);
     fp.p[f] = p;
   }
+  if (getenv("LAB_SAMEFIELD")) {                    // one array four times: a quarter of the HBM bytes, the same instructions
+    for (int f = 1; f < 4; ++f) fp.p[f] = fp.p[0];
+    printf("LAB_SAMEFIELD: the four field pointers are one array\n");
+  }
   CHK(hipDeviceSynchronize());
   const size_t csum_n = (size_t)ng * ndt * 8 * 64;
   double *csum_ref, *csum_t, *B_ref, *B_t, *partial, *dm;
@@ -246,6 +264,8 @@ int run(int64_t N, int64_t D, int reps, const char* only) {
   int bad = 0;
 
   struct Variant { std::string name; int nsplit; std::function<void(double*)> launch; };
+  double *px = nullptr, *pp = nullptr; size_t os_px_n = 0, os_pp_n = 0;   // outputs of the single-sweep variants
+  std::vector<double> os_ref;
   std::vector<Variant> vars;
   const int64_t cunits = std::max<int64_t>(1, gb0[ng] / 4);
   {   // reference: one wave per SIMD, quads of d-tiles
@@ -269,7 +289,7 @@ int run(int64_t N, int64_t D, int reps, const char* only) {
   // the store-free single sweep (timing only here: random basis and reference tables)
   {
     constexpr int TBX = 13, KX = 101, K4r = 52;
-    static double *ycx = nullptr, *rho = nullptr, *px = nullptr, *pp = nullptr;
+    static double *ycx = nullptr, *rho = nullptr;
     if (!ycx) {
       std::vector<double> h((size_t)(ng + 1) * 2 * TBX * 16);
       for (auto& v : h) v = std::generate_canonical<double, 53>(gen) - 0.5;
@@ -277,8 +297,10 @@ int run(int64_t N, int64_t D, int reps, const char* only) {
       std::vector<double> r((size_t)4 * K4r * D);
       for (auto& v : r) v = std::generate_canonical<double, 53>(gen) - 0.5;
       rho = to_dev(r);
-      CHK(hipMalloc(&px, (size_t)16 * 4 * KX * D * 8));
-      CHK(hipMalloc(&pp, (size_t)16 * 3 * K * D * 8));
+      os_px_n = (size_t)16 * 4 * KX * D; os_pp_n = (size_t)16 * 3 * K * D;
+      CHK(hipMalloc(&px, os_px_n * 8));
+      CHK(hipMalloc(&pp, os_pp_n * 8));
+      CHK(hipMemset(px, 0, os_px_n * 8)); CHK(hipMemset(pp, 0, os_pp_n * 8));
     }
     auto add_os = [&](auto nbrc, auto pdc, auto dfc) {
       constexpr int NBR = decltype(nbrc)::value, PD = decltype(pdc)::value;
@@ -294,10 +316,27 @@ int run(int64_t N, int64_t D, int reps, const char* only) {
         hipLaunchKernelGGL(kern, dim3(sp.grid), dim3(256), ldsb, 0, fp, D, K, KX, ycx_, reinterpret_cast<const int4*>(d_crow), cuts,
                            d_cs, rho_, K4r, px_, pp_, sp.nsplit, sp.ndt); }});
     };
+    auto add_osr = [&](auto nbrc, auto pdc) {
+      constexpr int NBR = decltype(nbrc)::value, PD = decltype(pdc)::value;
+      Split sp = choose_split(D, cunits, 256, 4, 8);
+      int2* cuts = reinterpret_cast<int2*>(to_dev(group_cuts(gb0, sp.nsplit)));
+      const size_t ldsb = ((size_t)2 * 2 * TBX * 16 + 16 + (size_t)4 * 4 * 2 * NBR * 64 + (size_t)4 * 3 * 2 * TBS * 64 + (size_t)14 * 256) * 8;
+      auto kern = sweep_osr_kernel<T, TBS, TBX, NBR, PD, 0>;
+      CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+      double *ycx_ = ycx, *rho_ = rho, *px_ = px, *pp_ = pp;
+      vars.push_back({"osr   ONE sweep, loads of 1 row x 64 columns, exchange at the group's end, PD=" + std::to_string(PD), 0, [=](double*) {
+        hipLaunchKernelGGL(kern, dim3(sp.grid), dim3(256), ldsb, 0, fp, D, K, KX, ycx_, reinterpret_cast<const int4*>(d_crow), cuts,
+                           d_cs, rho_, K4r, px_, pp_, sp.nsplit, sp.ndt); }});
+    };
+    add_osr(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+    add_osr(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{});
+    add_osr(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});     // (vmcnt counts to 63: 3 x 16 + 12 loads)
     using N0 = std::integral_constant<int, 0>; using N1 = std::integral_constant<int, 1>;
     add_os(std::integral_constant<int, 2>{}, std::integral_constant<int, sizeof(T) == 8 ? 2 : 4>{}, N0{});
     add_os(std::integral_constant<int, 2>{}, std::integral_constant<int, sizeof(T) == 8 ? 2 : 4>{}, N1{});
-    add_os(std::integral_constant<int, 2>{}, std::integral_constant<int, sizeof(T) == 8 ? 2 : 4>{}, std::integral_constant<int, 2>{});
+#ifndef LAB_OS_FEW
+    add_os(std::integral_constant<int, 2>{}, std::integral_constant<int, sizeof(T) == 8 ? 3 : 6>{}, N0{});
+#endif
   }
 #endif
 #ifdef LAB_FUSED
@@ -373,6 +412,16 @@ int run(int64_t N, int64_t D, int reps, const char* only) {
       best = std::min(best, ms); sum += ms;
     }
     CHK(hipGetLastError());
+    if (px && !strncmp(v.name.c_str(), "os", 2)) {     // the single-sweep variants against the first of them
+      std::vector<double> h(os_px_n + os_pp_n);
+      CHK(hipMemcpy(h.data(), px, os_px_n * 8, hipMemcpyDeviceToHost));
+      CHK(hipMemcpy(h.data() + os_px_n, pp, os_pp_n * 8, hipMemcpyDeviceToHost));
+      if (os_ref.empty()) os_ref = h;
+      double dm_ = 0.0, rm_ = 0.0;
+      for (size_t i = 0; i < h.size(); ++i) { dm_ = std::max(dm_, std::fabs(h[i] - os_ref[i])); rm_ = std::max(rm_, std::fabs(os_ref[i])); }
+      printf("    outputs vs the first single-sweep variant: max |diff| / max |ref| = %.2e (max |ref| %.3e)\n", dm_ / rm_, rm_);
+      CHK(hipMemset(px, 0, os_px_n * 8)); CHK(hipMemset(pp, 0, os_pp_n * 8));
+    }
 #ifdef LAB_OFFSETS
     if (!have_ref) {   // does the placement of the class-sum buffer relative to the fields matter?
       static double* big = nullptr;
