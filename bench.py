@@ -306,7 +306,7 @@ def main():
             # one-pass class path: the dominant kernel is sweep 1 (the only read of the fields)
             gbs_p = 4 * esize * pts_rank / (proj_ms * 1e-3) / 1e9
             single = bool(getattr(plan, "single_sweep", False)) and args.dtype == "f64"   # (fp32 inputs keep the class-sum form)
-            rec["roofline"] = {"kernel": ("sweep_os_kernel (the single sweep: theta, class sums of the four fields minus a low-degree "
+            rec["roofline"] = {"kernel": ("sweep_osr_kernel (the single sweep, loads of 1 row x 64 columns: theta, class sums of the four fields minus a low-degree "
                                           "reference projected to degree 2L, their three products to degree L; no class-sum stream)"
                                           if single else
                                           "sweep_op_kernel (sweep 1 of the one-pass class path: theta + class sums of the fields, "

@@ -1167,7 +1167,7 @@ __device__ __forceinline__ void row_touch(T& a) {      // orders the uses of a b
 }
 
 // ------------------------------------------------------------------------------------------------
-// The single sweep with row-contiguous loads.  tools/ubench_gather.hip: the same bytes, rows and ring depth read
+// The single sweep with row-contiguous loads.  tools/ubench_lanemap.hip: the same bytes, rows and ring depth read
 // at 5.5 TB/s when one load instruction takes 4 rows x 16 columns (the MFMA B tile, as every other sweep here
 // loads) and at 6.3 TB/s when it takes 1 row x 64 columns (fp32: 3.1 vs 5.1 TB/s; 512-byte rows: 3.2 vs 6.1).
 // The class sums are lane-wise sums over the rows of a class, so the lane map of the loads is free:
@@ -1317,7 +1317,7 @@ sweep_osr_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
       issue(std::integral_constant<int, (P + PD - 1) % PD>{}, r1);
     }
     if (left > 0) {                           // the loads of the next batch are in flight meanwhile
-      pending_chunk(std::integral_constant<int, POS>{});
+      if (!(TEMX_OS_SKIP & 1)) pending_chunk(std::integral_constant<int, POS>{});
       --left;
     }
     // PD - 1 batches were issued after this one; its rows become usable one by one
@@ -1340,7 +1340,7 @@ sweep_osr_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
     }
     prev_south = south;
 #pragma unroll
-    for (int j = 0; j < MB; ++j) {
+    for (int j = 0; j < ((TEMX_OS_SKIP & 4) ? 0 : MB); ++j) {
       const double w = er[P][j] < 0 ? 0.0 : 1.0;   // (a padding entry: the whole row of this wave)
       double dx[NF];
 #pragma unroll
@@ -1375,7 +1375,7 @@ sweep_osr_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
         val[2 * NF + NP + k] = (q[k] - s[KD::pa(k)] * s[KD::pb(k)] * rnS) * sc;
       }
       // every wave is done with the exchange area of the previous group (LDS reads retired, loads stay in flight)
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (!(TEMX_OS_SKIP & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       ycur ^= 1;
       double* yw = ybase + ycur * YE;
 #pragma unroll
@@ -1387,7 +1387,7 @@ sweep_osr_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
 #pragma unroll
       for (int j = 0; j < YJ; ++j)
         if (tid + 256 * j < YE) yw[tid + 256 * j] = ys[j];
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (!(TEMX_OS_SKIP & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       ++grp;
       load_ys(grp);
       // ---- tile role: class slot g, column c of d-tile `wave`
@@ -1408,7 +1408,7 @@ sweep_osr_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
 #pragma unroll
       for (int f = 0; f < NF; ++f) E[f] = O[f] = 0.0;
 #pragma unroll
-      for (int tb = 0; tb < 2 * NBR; ++tb) {
+      for (int tb = 0; tb < ((TEMX_OS_SKIP & 2) ? 0 : 2 * NBR); ++tb) {
         const int blk = tb < NBR ? tb : TBX + (tb - NBR);
         const double ya = yw[blk * 16 + aoff_r];
 #pragma unroll

@@ -33,10 +33,10 @@ with open("profiles/%s_pmc_counters_ne120x72x30.csv" % rnd, "w") as fh:
     fh.write("kernel,counter,dispatches,avg_value_per_dispatch\n")
     for r in sorted(out):
         fh.write("\"%s\",%s,%d,%.6g\n" % r)
-single = any("sweep_os_kernel<double" in k for k, _ in tot)
+single = any("sweep_os_kernel<double" in k or "sweep_osr_kernel<double" in k for k, _ in tot)
 if single:
     e = [k for k, _ in tot if "os_contract_kernel" in k][0]
-    p = [k for k, _ in tot if "sweep_os_kernel<double" in k][0]
+    p = [k for k, _ in tot if "sweep_os_kernel<double" in k or "sweep_osr_kernel<double" in k][0]
     # (the reference pre-pass is the same kernel on a subsample: the per-dispatch average mixes both; the sum of the two is
     #  what one step moves, so report 2 x the average)
 else:

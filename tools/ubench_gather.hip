@@ -1,106 +1,120 @@
-// Development aid: what does the shape of the sweep's loads cost?  Four [N][D] fp64 (or fp32) arrays are read once,
-// rows in class order (a random permutation here), by workgroups of four waves that each own 64 columns x a slice of
-// the rows -- the structure of the latitude-class sweeps -- with two lane maps:
-//   A  "tile":  a wave owns 16 columns; one load instruction = 4 rows x 128 B (the sweeps as they are)
-//   B  "row":   a wave owns one row slot of the batch and all 64 columns; one load instruction = 1 row x 512 B
-// Same bytes, same rows per batch (16 per workgroup), same ring depth.  hipcc -O3 --offload-arch=gfx950
+// ubench_gather.hip -- how fast can rows be gathered and summed, as the class sweeps do it?
+//   A: 8-byte loads, lane = (row slot g = lane>>4, column c = lane&15): 4 rows x 128 B per instruction
+//   B: 16-byte loads, lane = (row slot g = lane>>4, column pair): 4 rows x 256 B per instruction
+//   C: 16-byte loads, lane = (row slot g = lane>>5, column pair): 2 rows x 512 B per instruction
+// Rows of D doubles in random order (a permutation), 4 "fields", every byte read once.
+// build: hipcc -O3 --offload-arch=gfx950 -o ubench_gather ubench_gather.hip ; run: ./ubench_gather
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
-#include <cstring>
 #include <vector>
-#include <random>
 #include <algorithm>
-#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+#include <random>
 
-template <typename T> struct F4 { const T* p[4]; };
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s\n", hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <typename T, int MAP, int PD>
-__global__ void __launch_bounds__(256, 1)
-gather_kernel(F4<T> fp, int64_t D, const int* __restrict__ rows, int nbatch, int nsplit, double* __restrict__ out) {
-  const int ndq = (int)((D + 63) / 64);
-  const int wg = blockIdx.x;
-  if (wg >= ndq * nsplit) return;
-  const int dq = wg % ndq, split = wg / ndq;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int b0 = (int)((int64_t)nbatch * split / nsplit), b1 = (int)((int64_t)nbatch * (split + 1) / nsplit);
-  // a batch = 16 rows: rows[b * 16 + k * 4 + j], k = class slot, j = member
-  int64_t col;
-  if (MAP == 0) col = (int64_t)dq * 64 + wave * 16 + (lane & 15);
-  else col = (int64_t)dq * 64 + lane;
-  if (col >= D) col = D - 1;
-  T xb[PD][4][4];
-  double acc[4] = {0, 0, 0, 0};
-  auto issue = [&](int slot, int b) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int r;
-      if (MAP == 0) r = rows[b * 16 + (lane >> 4) * 4 + j];
-      else r = __builtin_amdgcn_readfirstlane(rows[b * 16 + wave * 4 + j]);
-      const int64_t off = (int64_t)r * D + col;
-#pragma unroll
-      for (int f = 0; f < 4; ++f) xb[slot][j][f] = __builtin_nontemporal_load(fp.p[f] + off);
-    }
-  };
-#pragma unroll
-  for (int k = 0; k < PD - 1; ++k) if (b0 + k < b1) issue(k, b0 + k);
-  for (int b = b0; b < b1; b += PD) {
-#pragma unroll
-    for (int k = 0; k < PD; ++k) {
-      if (b + k < b1) {
-        if (b + k + PD - 1 < b1) issue((k + PD - 1) % PD, b + k + PD - 1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int f = 0; f < 4; ++f) acc[f] += (double)xb[k][j][f];
+// ST > 0: after every 64 rows the wave also stores ST x 512 B (the class-sum record of the one-pass sweep)
+template <int W, int RPI, int ST = 0, int NI = 4>   // W = doubles per lane per load (1 or 2), RPI = rows per load instruction, NI = load instructions per field in flight
+__global__ void __launch_bounds__(256, 2) gather(const double* const* f, const int* rows, int nrows, int D,
+                                                 int colgroups, double* sink, double* out = nullptr) {
+  constexpr int LPR = 64 / RPI;            // lanes per row
+  constexpr int CPW = LPR * W;             // columns per wave
+  const int wave = (blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int cg = wave % colgroups, rw = wave / colgroups, nrw = (gridDim.x * 4) / colgroups;
+  const int g = lane / LPR, c = (lane % LPR) * W;
+  const int col = cg * CPW + c;
+  if (col >= D) return;
+  double s[4][W];
+  for (int i = 0; i < 4; ++i) for (int w = 0; w < W; ++w) s[i][w] = 0.0;
+  const int r0 = (int)((long)nrows * rw / nrw), r1 = (int)((long)nrows * (rw + 1) / nrw);
+  long rec = ((long)rw * colgroups + cg) * ((nrows / nrw) / 64 + 2);
+  int since = 0;
+  for (int r = r0; r + NI * RPI <= r1; r += NI * RPI) {      // NI instructions per field in flight
+    int rr[NI];
+    for (int j = 0; j < NI; ++j) rr[j] = rows[r + j * RPI + g];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < NI; ++j) {
+        const double* p = f[i] + (long)rr[j] * D + col;
+        if (W == 1) s[i][0] += *p;
+        else { double2 v = *reinterpret_cast<const double2*>(p); s[i][0] += v.x; s[i][1] += v.y; }
+      }
+    if (ST > 0) {
+      since += NI * RPI;
+      if (since >= 64) {
+        since = 0;
+        if (ST == 7) {          // the same bytes as 7 x 16-byte pairs (what the one-pass sweep stores)
+          double2* o2 = reinterpret_cast<double2*>(out + rec * (14 * 64)) + lane;
+          for (int k = 0; k < 7; ++k) o2[k * 64] = make_double2(s[k & 3][0] + k, s[k & 3][0] - k);
+        } else {
+          double* o = out + rec * (ST * 64) + lane;
+          for (int k = 0; k < ST; ++k) o[k * 64] = s[k & 3][0] + k;
+        }
+        ++rec;
       }
     }
   }
-  out[(int64_t)blockIdx.x * 256 + threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3];
+  double t = 0.0;
+  for (int i = 0; i < 4; ++i) for (int w = 0; w < W; ++w) t += s[i][w];
+  if (t == 1.2345e300) sink[0] = t;
 }
 
-template <typename T> __global__ void fill(T* p, int64_t n) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = (T)(i & 1023);
-}
-
-template <typename T> int run(int64_t N, int64_t D, int reps) {
-  F4<T> fp;
-  for (int f = 0; f < 4; ++f) { T* p; CHK(hipMalloc(&p, (size_t)N * D * sizeof(T))); hipLaunchKernelGGL(fill<T>, dim3(4096), dim3(256), 0, 0, p, N * D); fp.p[f] = p; }
-  std::vector<int> rows((size_t)((N + 15) / 16) * 16);
-  for (size_t i = 0; i < rows.size(); ++i) rows[i] = (int)(i % N);
-  if (!getenv("UB_SEQUENTIAL")) { std::mt19937 g(3); std::shuffle(rows.begin(), rows.begin() + N, g); }
-  int* d_rows; CHK(hipMalloc(&d_rows, rows.size() * 4)); CHK(hipMemcpy(d_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
-  const int nbatch = (int)(rows.size() / 16);
-  const int ndq = (int)((D + 63) / 64);
-  const int nsplit = std::max(1, (getenv("UB_WGS") ? atoi(getenv("UB_WGS")) : 512) / ndq);   // ~2 workgroups per CU over the run, one resident
-  const int grid = ndq * nsplit;
-  double* out; CHK(hipMalloc(&out, (size_t)grid * 256 * 8));
-  hipEvent_t a, b; CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
-  const double gb = 4.0 * N * D * sizeof(T) / 1e9;
-  const size_t lds = 100 << 10;                     // one workgroup per CU, as the sweeps' LDS use makes it
-  auto bench = [&](const char* name, auto kern) {
-    CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, fp, D, d_rows, nbatch, nsplit, out);
-    CHK(hipEventRecord(a));
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, fp, D, d_rows, nbatch, nsplit, out);
-    CHK(hipEventRecord(b)); CHK(hipEventSynchronize(b));
-    float ms; CHK(hipEventElapsedTime(&ms, a, b)); ms /= reps;
-    printf("%-58s %8.3f ms  %6.2f TB/s\n", name, ms, gb / ms);
-  };
-  printf("N = %lld rows, D = %lld columns, %zu-byte elements, %.2f GB per pass, grid %d (nsplit %d)\n", (long long)N, (long long)D, sizeof(T), gb, grid, nsplit);
-  bench("A tile map (4 rows x 16 columns per instruction), ring 2", gather_kernel<T, 0, 2>);
-  bench("A tile map, ring 3", gather_kernel<T, 0, 3>);
-  bench("A tile map, ring 4", gather_kernel<T, 0, 4>);
-  bench("B row map (1 row x 64 columns per instruction), ring 2", gather_kernel<T, 1, 2>);
-  bench("B row map, ring 3", gather_kernel<T, 1, 3>);
-  bench("B row map, ring 4", gather_kernel<T, 1, 4>);
+int main() {
+  const int N = 777602, D = 2160;
+  const size_t bytes = (size_t)N * D * 8;
+  double* fd[4];
+  for (int i = 0; i < 4; ++i) { CHK(hipMalloc(&fd[i], bytes)); CHK(hipMemset(fd[i], 0, bytes)); }
+  const double** fdev; CHK(hipMalloc(&fdev, 4 * sizeof(double*)));
+  CHK(hipMemcpy(fdev, fd, 4 * sizeof(double*), hipMemcpyHostToDevice));
+  std::vector<int> perm(N);
+  for (int i = 0; i < N; ++i) perm[i] = i;
+  std::mt19937 gen(1);
+  for (int ordered = 1; ordered >= 0; --ordered) {
+    if (!ordered) std::shuffle(perm.begin(), perm.end(), gen);
+    int* rows; CHK(hipMalloc(&rows, (N + 64) * sizeof(int)));
+    CHK(hipMemcpy(rows, perm.data(), N * sizeof(int), hipMemcpyHostToDevice));
+    double* sink; CHK(hipMalloc(&sink, 8));
+    hipEvent_t a, b; CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
+    auto run = [&](const char* name, auto kern, int cpw) {
+      const int colgroups = (D + cpw - 1) / cpw;
+      const int waves = ((256 * 8 * 4) / colgroups) * colgroups;   // ~8 waves per CU, several rounds
+      const int blocks = waves / 4;
+      float best = 1e9f;
+      for (int rep = 0; rep < 4; ++rep) {
+        CHK(hipEventRecord(a));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, (const double* const*)fdev, rows, N, D, colgroups, sink, (double*)nullptr);
+        CHK(hipEventRecord(b)); CHK(hipEventSynchronize(b));
+        float ms; CHK(hipEventElapsedTime(&ms, a, b)); best = std::min(best, ms);
+      }
+      printf("%-8s rows %-8s  %-44s %7.3f ms  %6.2f TB/s\n", ordered ? "ordered" : "shuffled", "", name, best,
+             4.0 * bytes / best / 1e9);
+    };
+    double* outbuf; CHK(hipMalloc(&outbuf, (size_t)16 << 30));
+    auto run_st = [&](const char* name, auto kern, int cpw) {
+      const int colgroups = (D + cpw - 1) / cpw;
+      const int waves = ((256 * 8 * 4) / colgroups) * colgroups;
+      const int blocks = waves / 4;
+      float best = 1e9f;
+      for (int rep = 0; rep < 4; ++rep) {
+        CHK(hipEventRecord(a));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, (const double* const*)fdev, rows, N, D, colgroups, sink, outbuf);
+        CHK(hipEventRecord(b)); CHK(hipEventSynchronize(b));
+        float ms; CHK(hipEventElapsedTime(&ms, a, b)); best = std::min(best, ms);
+      }
+      const double wr = (double)N / 64 * colgroups * 14 * 512;
+      printf("%-8s rows %-8s  %-44s %7.3f ms  %6.2f TB/s read, %6.2f TB/s read+write\n", ordered ? "ordered" : "shuffled", "",
+             name, best, 4.0 * bytes / best / 1e9, (4.0 * bytes + wr) / best / 1e9);
+    };
+    run("A: 8 B/lane, 4 rows x 128 B per instruction", gather<1, 4>, 16);
+    run("B: 16 B/lane, 4 rows x 256 B per instruction", gather<2, 4>, 32);
+    run("C: 16 B/lane, 2 rows x 512 B per instruction", gather<2, 2>, 64);
+    run("D: 8 B/lane, 1 row x 512 B per instruction", gather<1, 1>, 64);
+    run_st("E: as A + 14 x 512 B stored per 64 rows", gather<1, 4, 14>, 16);
+    run_st("F: as A + 7 x 1 KB (16 B/lane) per 64 rows", gather<1, 4, 7>, 16);
+    run_st("G: as F, 8 load instructions per field in flight", gather<1, 4, 7, 8>, 16);
+    run_st("H: as F, 16 load instructions per field in flight", gather<1, 4, 7, 16>, 16);
+    CHK(hipFree(rows));
+    CHK(hipFree(outbuf));
+  }
   return 0;
-}
-
-int main(int argc, char** argv) {
-  const int64_t N = argc > 1 ? atoll(argv[1]) : 777602;
-  const int64_t D = argc > 2 ? atoll(argv[2]) : 2160;
-  const int reps = argc > 3 ? atoi(argv[3]) : 5;
-  if (argc > 4 && !strcmp(argv[4], "f32")) return run<float>(N, D, reps);
-  return run<double>(N, D, reps);
 }
