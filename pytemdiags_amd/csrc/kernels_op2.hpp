@@ -1153,6 +1153,12 @@ template <> struct RowLoad<float> {
     asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
   }
 };
+// 1 / n for a member count n (a small positive integer): v_rcp_f64 and one Newton step instead of the division's
+// twenty instructions, twice per class-group and wave
+__device__ __forceinline__ double temx_rcp_count(double n) {
+  double r = __builtin_amdgcn_rcp(n);
+  return __builtin_fma(__builtin_fma(-n, r, 1.0), r, r);
+}
 template <int N, typename T>
 __device__ __forceinline__ void row_wait(T& a, T& b, T& c, T& d) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
@@ -1251,7 +1257,7 @@ sweep_osr_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
 #pragma unroll
   for (int k = 0; k < NP; ++k) q[k] = qN[k] = 0.0;
   bool north_open = false, prev_south = false;
-  const uint32_t D32 = (uint32_t)D;
+  const uint32_t rowbytes = (uint32_t)D * (uint32_t)sizeof(T);   // host guarantees D < 2^28
 
   T xb[PD][MB][NF];
   int er[PD][MB];                             // wave-uniform: the rows of this wave's class slot
@@ -1266,7 +1272,7 @@ sweep_osr_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
     er[P][0] = rv.x; er[P][1] = rv.y; er[P][2] = rv.z; er[P][3] = rv.w;
 #pragma unroll
     for (int j = 0; j < MB; ++j) {
-      const uint64_t off = (uint64_t)(uint32_t)(er[P][j] & CLS_ROWMASK) * D32 * sizeof(T);   // wave-uniform
+      const uint64_t off = (uint64_t)(uint32_t)(er[P][j] & CLS_ROWMASK) * rowbytes;   // wave-uniform, one 32 x 32 -> 64 multiply
 #pragma unroll
       for (int f = 0; f < NF; ++f) RowLoad<T>::ld(xb[P][j][f], colb32, fbase[f] + off);
     }
@@ -1360,7 +1366,7 @@ sweep_osr_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
           if (((decltype(cc)::value - POS - 1) & (NCH - 1)) < left) pending_chunk(cc);
         });
       // ---- reading role: side means (theta = T x the column scale) and central co-moments of my class
-      const double rnN = cntN > 0.0 ? 1.0 / cntN : 0.0, rnS = cnt > 0.0 ? 1.0 / cnt : 0.0;
+      const double rnN = cntN > 0.0 ? temx_rcp_count(cntN) : 0.0, rnS = cnt > 0.0 ? temx_rcp_count(cnt) : 0.0;
       double val[NV];
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
@@ -1486,6 +1492,249 @@ sweep_osr_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
       for (int t = 0; t < 2 * TBS; ++t) {
         const int l = sym_harm<TBS>(t, g);
         if (l < K) pp[(((int64_t)split * NP + k) * K + l) * D + d] = apl[(k * 2 * TBS + t) * 64];
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sweep 1 of the class-sum form with row-contiguous loads: sweep_op_kernel (kernels_op.hpp: same inputs, class-sum
+// records, partial slabs and arithmetic) read the way sweep_osr_kernel reads.  While it reads, wave w owns class
+// slot w of every class-group and the workgroup's 64 columns; at the end of a group it stores its class's sums
+// into the four records of the group (16 columns = 256 B of each of the four d-tiles per instruction), the
+// {sum, difference} operands of (class, column) cross through LDS, and wave w projects d-tile w, deferred over
+// the next four batches.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int TBS, int PD, int KIND>
+__global__ void __launch_bounds__(256, OpKind<KIND>::WPS)
+sweep_opr_kernel(FieldPtrs<4> fp, int64_t D, int K, const double* __restrict__ ycls,
+                 const int4* __restrict__ crow,
+                 const int2* __restrict__ csplit, const double* __restrict__ colscale,
+                 double* __restrict__ partial, int nsplit, int ndt, double* __restrict__ csum) {
+  using KD = OpKind<KIND>;
+  constexpr int NB = 2 * TBS;
+  constexpr int YE = NB * 16;
+  constexpr int MB = CLS_MB;
+  constexpr int NFLD = KD::NFLD, NST = KD::NST, NQ = KD::NQ;
+  constexpr int NA = NST + NQ;                // projections: the stored sums, then the co-moments
+  constexpr int NCH = 4;
+  static_assert(KIND == 0 || KIND == 1, "TEM or tracer");
+  static_assert(YE <= 256, "one Y element per thread");
+  static_assert(PD + 1 <= CLS_PADB, "table padding must cover the index prefetch");
+  static_assert((PD - 1) * MB * NFLD + (MB - 1) * NFLD + NST + 1 <= 63, "the ring is counted in vmcnt (6 bits)");
+  __shared__ double ybuf[2][YE];              // the group's Y blocks, shared by the four waves
+  __shared__ double ex[2 * NA][4][64];        // [sums then differences][class slot][column]
+  int split, dq;
+  if (!wg_work((ndt + 3) / 4, nsplit, split, dq)) return;
+  const int tid = threadIdx.x;
+  const int wave = uniform_wave(), lane = tid & 63;
+  const int c = lane & 15, g = lane >> 4;
+  // reading role: class slot `wave`, column dq * 64 + lane
+  const int64_t colr_ = (int64_t)dq * 64 + lane;
+  const bool rvalid = colr_ < D;
+  const int64_t colr = rvalid ? colr_ : D - 1;
+  const uint32_t colb32 = (uint32_t)colr * (uint32_t)sizeof(T);
+  // tile role: d-tile dq * 4 + wave, lane = (class slot g, column c)
+  const int dt = dq * 4 + wave;
+  const int64_t d = (int64_t)dt * 16 + c;
+  const bool dvalid = dt < ndt && d < D;
+  const int b0 = __builtin_amdgcn_readfirstlane(csplit[split].x);
+  const int b1 = __builtin_amdgcn_readfirstlane(csplit[split + 1].x);
+  int grp = __builtin_amdgcn_readfirstlane(csplit[split].y);
+  const uint32_t yoff = (uint32_t)(g * 4 + (lane & 3));
+  const double sth = (KIND == 0 && colscale != nullptr) ? colscale[colr] : 1.0;
+  uint64_t fbase[NFLD];
+#pragma unroll
+  for (int f = 0; f < NFLD; ++f) fbase[f] = reinterpret_cast<uint64_t>(fp.p[f]);
+
+  double acc[NA][NB];
+#pragma unroll
+  for (int f = 0; f < NA; ++f)
+#pragma unroll
+    for (int t = 0; t < NB; ++t) acc[f][t] = 0.0;
+  double s[NFLD], q[NQ], x0[NFLD], cnt = 0.0;
+  double sN[NST], qN[NQ];
+#pragma unroll
+  for (int f = 0; f < NFLD; ++f) s[f] = x0[f] = 0.0;
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) q[k] = qN[k] = 0.0;
+#pragma unroll
+  for (int f = 0; f < NST; ++f) sN[f] = 0.0;
+  bool north_open = false, prev_south = false;
+  const uint32_t rowbytes = (uint32_t)D * (uint32_t)sizeof(T);   // host guarantees D < 2^28
+
+  T xb[PD][MB][NFLD];
+  int er[PD][MB];                             // wave-uniform: the rows of this wave's class slot
+  double ys;
+  const uint32_t yoff32 = (uint32_t)(tid < YE ? tid : 0) * 8u;
+  auto load_ys = [&](int gi) __attribute__((always_inline)) {
+    RowLoad<double>::ld(ys, yoff32, reinterpret_cast<uint64_t>(ycls) + (uint64_t)gi * (YE * 8));
+  };
+  auto issue = [&](auto pc, const int4 rv) __attribute__((always_inline)) {
+    constexpr int P = decltype(pc)::value;
+    er[P][0] = rv.x; er[P][1] = rv.y; er[P][2] = rv.z; er[P][3] = rv.w;
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+      const uint64_t off = (uint64_t)(uint32_t)(er[P][j] & CLS_ROWMASK) * rowbytes;   // wave-uniform, one 32 x 32 -> 64 multiply
+#pragma unroll
+      for (int f = 0; f < NFLD; ++f) RowLoad<T>::ld(xb[P][j][f], colb32, fbase[f] + off);
+    }
+  };
+  auto finish_side = [&](double* so, double* qo) __attribute__((always_inline)) {
+    const double rn = cnt > 0.0 ? temx_rcp_count(cnt) : 0.0;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) qo[k] = q[k] - s[KD::pa(k)] * s[KD::pb(k)] * rn;
+#pragma unroll
+    for (int f = 0; f < NST; ++f) so[f] = s[f] + cnt * x0[f];
+#pragma unroll
+    for (int f = 0; f < NFLD; ++f) s[f] = 0.0;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) q[k] = 0.0;
+    cnt = 0.0;
+  };
+  // operands of the group whose projection is pending (tile role), its Y buffer, chunks still to run
+  double pS[NA], pD[NA];
+#pragma unroll
+  for (int f = 0; f < NA; ++f) pS[f] = pD[f] = 0.0;
+  const double* yprev = ybuf[0];
+  int ycur = 0, left = 0;
+  auto pending_chunk = [&](auto cc) __attribute__((always_inline)) {
+    constexpr int C = decltype(cc)::value;
+#pragma unroll
+    for (int t = C * NB / NCH; t < (C + 1) * NB / NCH; ++t) {
+      const double ya = yprev[t * 16 + yoff];
+#pragma unroll
+      for (int f = 0; f < NA; ++f) acc[f][t] = TEMX_MFMA4(ya, t < TBS ? pS[f] : pD[f], acc[f][t]);
+    }
+  };
+  int4 rn;
+  auto step = [&](auto posc, int b) __attribute__((always_inline)) {
+    constexpr int POS = decltype(posc)::value % NCH;
+    constexpr int P = decltype(posc)::value % PD;
+    {                                         // (past b1: the next cut's rows or the table's padding, never used)
+      const int4 r1 = rn;
+      rn = crow[(int64_t)(b + PD) * 4 + wave];
+      issue(std::integral_constant<int, (P + PD - 1) % PD>{}, r1);
+    }
+    if (left > 0) {
+      pending_chunk(std::integral_constant<int, POS>{});
+      --left;
+    }
+    static_for<MB>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      constexpr int NW = (PD - 1) * MB * NFLD + (MB - 1 - j) * NFLD;
+      if constexpr (NFLD == 4) row_wait<NW>(xb[P][j][0], xb[P][j][1], xb[P][j][2], xb[P][j][3]);
+      else row_wait<NW>(xb[P][j][0], xb[P][j][1], xb[P][j][2]);
+    });
+    row_touch(ys);
+    const int fl = er[P][0] >> 27;            // haspad, south, first, last: those of the batch
+    const bool south = (fl & (CLS_SOUTH << 1)) != 0;
+    if ((fl & (CLS_FIRST << 1)) || (south && !prev_south)) {
+      if (south && north_open) finish_side(sN, qN);
+      north_open = !south;
+#pragma unroll
+      for (int f = 0; f < NFLD; ++f) x0[f] = (double)xb[P][0][f];
+    }
+    prev_south = south;
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+      const double w = er[P][j] < 0 ? 0.0 : 1.0;   // (a padding entry: the whole row of this wave)
+      double dx[NFLD];
+#pragma unroll
+      for (int f = 0; f < NFLD; ++f) dx[f] = (double)xb[P][j][f] - x0[f];
+#pragma unroll
+      for (int f = 0; f < NFLD; ++f) s[f] += w * dx[f];
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) q[k] += (w * dx[KD::pa(k)]) * dx[KD::pb(k)];
+      cnt += w;
+    }
+    if (fl & (CLS_LAST << 1)) {
+      prev_south = false;
+      double sS[NST], qS[NQ];
+#pragma unroll
+      for (int f = 0; f < NST; ++f) sS[f] = 0.0;
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) qS[k] = 0.0;
+      if (north_open)
+        finish_side(sN, qN);                  // the group has no southern batch
+      else
+        finish_side(sS, qS);
+      north_open = false;
+      if (KIND == 0) {                        // T -> theta: field 2 and the v theta co-moment
+        sN[NST > 2 ? 2 : 0] *= sth; sS[NST > 2 ? 2 : 0] *= sth;
+        qN[NQ - 1] *= sth; qS[NQ - 1] *= sth;
+      }
+      if (rvalid) {                           // record (grp, d-tile lane >> 4), row f, element [class slot][column]
+        double2* o = reinterpret_cast<double2*>(csum + TEMX_CSUM_REC(grp, dq * 4 + g, ndt) * (2 * NST) * 64) + wave * 16 + c;
+#pragma unroll
+        for (int f = 0; f < NST; ++f) TEMX_CSTORE(o + f * 64, make_double2(sN[f], sS[f]));
+      }
+      if (left > 0)                           // (a group shorter than NCH steps: what is left of the previous projection)
+        static_for<NCH>([&](auto cc) __attribute__((always_inline)) {
+          if (((decltype(cc)::value - POS - 1) & (NCH - 1)) < left) pending_chunk(cc);
+        });
+      // every wave is done with the exchange area of the previous group (LDS reads retired, loads stay in flight)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      ycur ^= 1;
+#pragma unroll
+      for (int f = 0; f < NST; ++f) {
+        ex[f][wave][lane] = sN[f] + sS[f];
+        ex[NA + f][wave][lane] = sN[f] - sS[f];
+      }
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) {          // the class co-moments are projected like field sums
+        ex[NST + k][wave][lane] = qN[k] + qS[k];
+        ex[NA + NST + k][wave][lane] = qN[k] - qS[k];
+      }
+      if (tid < YE) ybuf[ycur][tid] = ys;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      ++grp;
+      load_ys(grp);                           // ycls is padded by one group
+#pragma unroll
+      for (int f = 0; f < NA; ++f) {
+        pS[f] = ex[f][g][wave * 16 + c];
+        pD[f] = ex[NA + f][g][wave * 16 + c];
+      }
+      yprev = ybuf[ycur];
+      left = NCH;
+#pragma unroll
+      for (int f = 0; f < NST; ++f) sN[f] = 0.0;
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) qN[k] = 0.0;
+    }
+  };
+
+  if (b0 < b1) {
+    load_ys(grp);
+    rn = crow[(int64_t)b0 * 4 + wave];
+    static_for<PD - 1>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int k = decltype(kc)::value;
+      const int4 r0 = rn;
+      rn = crow[(int64_t)(b0 + k + 1) * 4 + wave];
+      issue(kc, r0);
+    });
+    constexpr int UNR = PD % 4 == 0 ? PD : PD % 2 == 0 ? 2 * PD : 4 * PD;   // lcm(PD, NCH)
+    for (int b = b0; b < b1; b += UNR)
+      static_for<UNR>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        if (k == 0 || b + k < b1) step(kc, b + k);
+      });
+    // loads issued past b1 and the last Y prefetch are still landing in registers the compiler believes free
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (left > 0) {
+    const int first = (b1 - b0) & (NCH - 1);
+    static_for<NCH>([&](auto cc) __attribute__((always_inline)) {
+      if (((decltype(cc)::value - first) & (NCH - 1)) < left) pending_chunk(cc);
+    });
+  }
+  // (an empty range still stores its zero slab: the reduction sums every slab)
+  if (dvalid) {
+#pragma unroll
+    for (int f = 0; f < NA; ++f)
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        const int l = sym_harm<TBS>(t, g);
+        if (l < K) partial[(((int64_t)split * NA + f) * K + l) * D + d] = acc[f][t];
       }
   }
 }

@@ -847,10 +847,24 @@ static int launch_sweep_op_t(temx_plan* pl, const FieldPtrs<4>& fp, double* part
   dim3 grid(sp.grid), block(256);
   // the tracer sweep (42 accumulators) runs two waves per SIMD: a ring of 2 batches keeps it inside 256 registers
   constexpr int PDv = KIND == 1 ? (sizeof(T) == 4 ? 4 : 2) : (sizeof(T) == 4 ? TEMX_CLS_OP_PD_F32 : TEMX_CLS_OP_PD);
+  // loads of 1 row x 64 columns (sweep_opr_kernel, kernels_op2.hpp) unless the last workgroup column would be
+  // mostly padding (D = 72: 64 + 8) or TEMX_OP_MAP=tile asks for the tile form (A/B)
+  const char* em = getenv("TEMX_OP_MAP");
+  const int64_t wcols = (pl->D + 63) / 64 * 64;
+  // fp64 only: with fp32 inputs the tile form measured faster (ne240 x 128 x 1: 1.77 vs 2.08 ms, ne120 x 72 x 30: 7.2 vs 7.5)
+  const bool row_map = sizeof(T) == 8 && !(em && !strcmp(em, "tile")) && wcols * 100 <= pl->D * 115;
+  constexpr int PDr = 2;
 #define TEMX_LSO(TBSv)                                                                                \
-  hipLaunchKernelGGL((sweep_op_kernel<T, TBSv, PDv, KIND>), grid, block, 0, st, fp, pl->D, pl->K, pl->ycls.d(), \
-                     static_cast<const int4*>(pl->crow.p), cuts, pl->colscale.d(), partial, sp.nsplit,       \
-                     sp.ndt, sums)
+  do {                                                                                                \
+    if (row_map)                                                                                      \
+      hipLaunchKernelGGL((sweep_opr_kernel<double, TBSv, PDr, KIND>), grid, block, 0, st, fp, pl->D, pl->K, pl->ycls.d(), \
+                         static_cast<const int4*>(pl->crow.p), cuts, pl->colscale.d(), partial, sp.nsplit,  \
+                         sp.ndt, sums);                                                               \
+    else                                                                                              \
+      hipLaunchKernelGGL((sweep_op_kernel<T, TBSv, PDv, KIND>), grid, block, 0, st, fp, pl->D, pl->K, pl->ycls.d(), \
+                         static_cast<const int4*>(pl->crow.p), cuts, pl->colscale.d(), partial, sp.nsplit,   \
+                         sp.ndt, sums);                                                               \
+  } while (0)
   switch (pl->TBS) {
     case 2: TEMX_LSO(2); break;
     case 4: TEMX_LSO(4); break;
@@ -1560,14 +1574,15 @@ static bool os_supported(const temx_plan* pl) {
   return (pl->TBS == 7 && tbx <= 13) || (pl->TBS == 4 && tbx <= 8) || (pl->TBS == 2 && tbx <= 4);
 }
 
-// the single-sweep forms run for fp64 inputs; fp32 inputs keep the class-sum forms (their records are a quarter
-// of the traffic, not an eighth, but the rows are read in 64-byte pieces either way and the heavier sweep
-// measured slower -- ne240 x 128 x 1: 2.5 vs 2.2 ms) unless TEMX_SINGLE_SWEEP=1 forces them
+// the single-sweep forms run for fp64 inputs and for fp32 inputs with many columns per row (ne120 x 72 x 30 fp32:
+// 8.3-8.6 against 9.0-9.3 ms); fp32 rows of a few hundred bytes keep the class-sum forms (ne240 x 128 x 1: 2.2 against
+// 2.5 ms -- with fp32 inputs the sweep's arithmetic per point, not its bytes, is the limit) unless
+// TEMX_SINGLE_SWEEP=1 forces them
 static bool os_active(const temx_plan* pl, int dtype) {
   if (!pl->os_on) return false;
   if (dtype == TEMX_F64) return true;
   const char* e = getenv("TEMX_SINGLE_SWEEP");
-  return e && e[0] == '1';
+  return (e && e[0] == '1') || pl->D >= 1024;
 }
 
 static int tem_run_os(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, double* results, double* zonal, void* stream) {
