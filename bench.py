@@ -305,11 +305,11 @@ def main():
         if plan.one_pass and nproj:
             # one-pass class path: the dominant kernel is sweep 1 (the only read of the fields)
             gbs_p = 4 * esize * pts_rank / (proj_ms * 1e-3) / 1e9
-            single = bool(getattr(plan, "single_sweep", False)) and args.dtype == "f64"   # (fp32 inputs keep the class-sum form)
+            single = bool(getattr(plan, "single_sweep", False)) and (args.dtype == "f64" or nlev * nt >= 1024)   # (short fp32 rows keep the class-sum form)
             rec["roofline"] = {"kernel": ("sweep_osr_kernel (the single sweep, loads of 1 row x 64 columns: theta, class sums of the four fields minus a low-degree "
                                           "reference projected to degree 2L, their three products to degree L; no class-sum stream)"
                                           if single else
-                                          "sweep_op_kernel (sweep 1 of the one-pass class path: theta + class sums of the fields, "
+                                          "sweep_opr_kernel for fp64 / sweep_op_kernel for fp32 inputs (sweep 1 of the class-sum form: theta + class sums of the fields, "
                                           "centred class co-moments of u v, u omega, v theta + 7 class projections)"),
                                "bound": "hbm", "achieved": gbs_p, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": gbs_p / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": proj_ms,

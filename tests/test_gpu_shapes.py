@@ -737,3 +737,47 @@ def test_single_sweep_form(monkeypatch, ne, nlev, nt, dtype, L):
     plan.set_tem(nlev, nt, plev * 100)
     assert plan.one_pass and not plan.single_sweep
     plan.close()
+
+
+@pytest.mark.parametrize("ne,nlev,nt,dtype", [
+    (16, 16, 8, np.float64),     # D = 128: two full workgroup columns
+    (12, 24, 15, np.float64),    # D = 360: ragged last workgroup column (384)
+    (12, 30, 6, np.float32),     # fp32 inputs (the class-sum sweep keeps the tile form for them)
+])
+def test_row_map_sweeps_equal_tile_map_sweeps(monkeypatch, ne, nlev, nt, dtype):
+    """The sweeps that load 1 row x 64 columns per instruction (sweep_osr_kernel, sweep_opr_kernel)
+    against the forms that load the MFMA B tile (TEMX_OS_MAP / TEMX_OP_MAP = tile): same sums in another order,
+    for the single-sweep run, its tracer, and the staged class-sum entry points."""
+    from pytemdiags_amd import _lib, engine, synth
+    import os
+    if any(os.environ.get(k) == "1" for k in ("TEMX_NO_SYM", "TEMX_NO_CLS", "TEMX_TWO_PASS", "TEMX_NO_QR")):
+        pytest.skip("needs the one-pass class path")
+    lat, lon = synth.cubed_sphere_gll(ne)
+    plev = synth.pressure_levels(nlev)
+    f = synth.analytic_fields(lat, lon, plev, nt, seed=43, dtype=dtype)
+    q = synth.analytic_tracer(lat, lon, plev, nt).astype(dtype)
+    d = [torch.as_tensor(x, device="cuda:0") for x in f]
+    dq = torch.as_tensor(q, device="cuda:0")
+    lat_zm = np.arange(-88.0, 89.0, 4.0)
+    monkeypatch.setenv("TEMX_ONE_PASS", "1")
+    monkeypatch.setenv("TEMX_SINGLE_SWEEP", "1")
+    out = {}
+    for form in ("row", "tile"):
+        if form == "tile":
+            monkeypatch.setenv("TEMX_OS_MAP", "tile")
+            monkeypatch.setenv("TEMX_OP_MAP", "tile")
+        plan = engine.Plan(lat, lat_zm, 50)
+        plan.set_tem(nlev, nt, plev * 100)
+        assert plan.single_sweep
+        res, zon = plan.tem_run(*d, want_zonal=True)
+        tres, _ = plan.tracer_run(dq, d[1], d[3])
+        B4 = plan.tem_stage1(*d)                               # class-sum form: sweep_opr_kernel / sweep_op_kernel
+        B3 = plan.tem_stage2_from_sums(B4)
+        sres, _ = plan.tem_stage3(B3)
+        assert not plan.status()
+        out[form] = [x.clone() for x in (res, zon, tres, B4, B3, sres)]
+        plan.close()
+    for a, b, what in zip(out["row"], out["tile"], ("results", "zonal", "tracer results", "B4", "B3", "staged results")):
+        for i in range(a.shape[0]):
+            scale = float(b[i].abs().max())
+            assert float((a[i] - b[i]).abs().max()) <= 1e-11 * scale, (what, i)
