@@ -1497,6 +1497,295 @@ sweep_osr_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// The single sweep with TWO waves per SIMD.  sweep_osr_kernel is one in-order wave per SIMD: with fp32 inputs its
+// instruction stream (7.5 ms at ne120 x 72 x 30) no longer fits under its loads (5.2 ms), and nothing runs while it
+// waits.  146 accumulators per d-tile leave no room for a second wave -- unless a wave holds half of them.  Here a
+// workgroup is 8 waves:
+//   * reading role: wave w owns class slot w & 3 on side w >> 2 (north / south) and the workgroup's 64 columns; it
+//     walks the row table of ITS side (side_tables.hpp), so it carries one side's sums only;
+//   * tile role: wave w owns d-tile w & 3 and PARITY w >> 2 of the harmonics: the even blocks take the sum of the
+//     two sides' operands, the odd blocks their difference -- 4 x 13 field accumulators in registers and 3 x 7
+//     product accumulators in LDS per wave.  Both parity waves reconstruct the whole reference (8 MFMAs twice).
+// The exchange, the barriers, the deferred projection (two chunks here: a side of a cubed-sphere class is two
+// batches) and the hand-issued loads are those of sweep_osr_kernel.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int TBS, int TBX, int NBR, int PD, int KIND = 0>
+__global__ void __launch_bounds__(512, 1)
+sweep_os2_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restrict__ ycx,
+                 const int4* __restrict__ crowN, const int4* __restrict__ crowS,
+                 const int* __restrict__ gfirstN, const int* __restrict__ gfirstS, const int2* __restrict__ csplit,
+                 const double* __restrict__ colscale, const double* __restrict__ rho, int K4,
+                 double* __restrict__ px, double* __restrict__ pp, int nsplit, int ndt) {
+  using KD = OsKind<KIND>;
+  constexpr int NF = KD::NF, NFX = KD::NFX, NP = KD::NP;
+  constexpr int NBX = 2 * TBX;
+  constexpr int YE = NBX * 16;
+  constexpr int MB = CLS_MB;
+  constexpr int NCH = 2;
+  constexpr int NV = NF + NP;                 // exchanged per (class side, column): mean of each field, central co-moments
+  static_assert(NBR <= TBS && TBS <= TBX, "reference degree <= L <= 2L");
+  static_assert(YE <= 512, "one Y element per thread");
+  static_assert((PD - 1) * MB * NF + (MB - 1) * NF + 1 <= 63, "the ring is counted in vmcnt (6 bits)");
+  // [2][YE] Y blocks | [16] member counts | [4 d-tiles][NF][2 NBR][64] reference operands |
+  // [8 waves][NP][TBS][64] product accumulators | [NV][8 class sides][64 columns] exchange
+  extern __shared__ double lds[];
+  int split, dq;
+  if (!wg_work((ndt + 3) / 4, nsplit, split, dq)) return;
+  const int tid = threadIdx.x;
+  const int wave = uniform_wave(), lane = tid & 63;
+  const int c = lane & 15, g = lane >> 4;
+  // reading role: class slot wave & 3 of side wave >> 2, column dq * 64 + lane
+  const int side = wave >> 2;
+  const int64_t colr = (int64_t)dq * 64 + lane < D ? (int64_t)dq * 64 + lane : D - 1;
+  const uint32_t colb32 = (uint32_t)colr * (uint32_t)sizeof(T);
+  // tile role: d-tile dq * 4 + (wave & 3), harmonics of parity wave >> 2, lane = (class slot g, column c)
+  const int tl = wave & 3, par = wave >> 2;
+  const int dt = dq * 4 + tl;
+  const int64_t d = (int64_t)dt * 16 + c;
+  const bool dvalid = dt < ndt && d < D;
+  const int64_t dcl = dvalid ? d : D - 1;
+  const int4* __restrict__ crow = side ? crowS : crowN;
+  const int* __restrict__ gfirst = side ? gfirstS : gfirstN;
+  int grp = __builtin_amdgcn_readfirstlane(csplit[split].y);
+  const int grp1 = __builtin_amdgcn_readfirstlane(csplit[split + 1].y);
+  const int b0 = __builtin_amdgcn_readfirstlane(gfirst[grp]);
+  const int b1 = __builtin_amdgcn_readfirstlane(gfirst[grp1]);
+  const uint32_t aoff_p = (uint32_t)(g * 4 + (lane & 3));
+  const uint32_t aoff_r = (uint32_t)((lane & 3) * 4 + g);
+  double* ybase = lds;
+  double* cn = lds + 2 * YE;
+  double* cb = lds + 2 * YE + 16 + tl * (NF * 2 * NBR * 64) + lane;
+  double* apl = lds + 2 * YE + 16 + 4 * (NF * 2 * NBR * 64) + wave * (NP * TBS * 64) + lane;
+  double* ex = lds + 2 * YE + 16 + 4 * (NF * 2 * NBR * 64) + 8 * (NP * TBS * 64);
+  double* exw = ex + wave * 64 + lane;                   // [v][my class side][my column]
+  const double* exr = ex + g * 64 + tl * 16 + c;         // [v][north side of class g][column of my d-tile]; south: + 256
+  const double sth = (KD::TF >= 0 && colscale != nullptr) ? colscale[colr] : 1.0;
+#pragma unroll
+  for (int i = 0; i < NP * TBS; ++i) apl[i * 64] = 0.0;
+  if (par == 0) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int tb = 0; tb < 2 * NBR; ++tb) {
+        const int l = tb < NBR ? 2 * (4 * tb + g) : 2 * (4 * (tb - NBR) + g) + 1;
+        const double v = rho[((int64_t)f * K4 + (l < K ? l : K - 1)) * D + dcl];
+        cb[(f * 2 * NBR + tb) * 64] = l < K ? v : 0.0;
+      }
+  }
+  uint64_t fbase[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) fbase[f] = reinterpret_cast<uint64_t>(fp.p[f]);
+
+  double ax[NFX][TBX];
+#pragma unroll
+  for (int f = 0; f < NFX; ++f)
+#pragma unroll
+    for (int t = 0; t < TBX; ++t) ax[f][t] = 0.0;
+  double s[NF], q[NP], x0[NF], cnt = 0.0;
+#pragma unroll
+  for (int f = 0; f < NF; ++f) s[f] = x0[f] = 0.0;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) q[k] = 0.0;
+  const uint32_t rowbytes = (uint32_t)D * (uint32_t)sizeof(T);   // host guarantees D < 2^28
+
+  T xb[PD][MB][NF];
+  int er[PD][MB];                             // wave-uniform: the rows of this wave's class side
+  double ys;
+  const uint32_t yoff32 = (uint32_t)(tid < YE ? tid : 0) * 8u;
+  auto load_ys = [&](int gi) __attribute__((always_inline)) {
+    RowLoad<double>::ld(ys, yoff32, reinterpret_cast<uint64_t>(ycx) + (uint64_t)gi * (YE * 8));
+  };
+  auto issue = [&](auto pc, const int4 rv) __attribute__((always_inline)) {
+    constexpr int P = decltype(pc)::value;
+    er[P][0] = rv.x; er[P][1] = rv.y; er[P][2] = rv.z; er[P][3] = rv.w;
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+      const uint64_t off = (uint64_t)(uint32_t)(er[P][j] & CLS_ROWMASK) * rowbytes;   // wave-uniform
+#pragma unroll
+      for (int f = 0; f < NF; ++f) RowLoad<T>::ld(xb[P][j][f], colb32, fbase[f] + off);
+    }
+  };
+  double dS[NFX], dP[NP];                     // operands of the pending projection: my parity's combination
+#pragma unroll
+  for (int f = 0; f < NFX; ++f) dS[f] = 0.0;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) dP[k] = 0.0;
+  const double* yprev = ybase + par * (TBX * 16);
+  int ycur = 0, left = 0;
+  auto pending_chunk = [&](auto cc) __attribute__((always_inline)) {
+    constexpr int C = decltype(cc)::value;
+#pragma unroll
+    for (int t = C * TBX / NCH; t < (C + 1) * TBX / NCH; ++t) {
+      const double ya = yprev[t * 16 + aoff_p];
+#pragma unroll
+      for (int f = 0; f < NFX; ++f) ax[f][t] = TEMX_MFMA4(ya, dS[f], ax[f][t]);
+      if (t < TBS) {                          // the product blocks are the first TBS of the parity
+        double v[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) v[k] = apl[(k * TBS + t) * 64];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) v[k] = TEMX_MFMA4(ya, dP[k], v[k]);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) apl[(k * TBS + t) * 64] = v[k];
+      }
+    }
+  };
+  int4 rn;
+  auto step = [&](auto posc, int b) __attribute__((always_inline)) {
+    constexpr int POS = decltype(posc)::value % NCH;
+    constexpr int P = decltype(posc)::value % PD;
+    {                                         // (past b1: the next cut's rows or the table's padding, never used)
+      const int4 r1 = rn;
+      rn = crow[(int64_t)(b + PD) * 4 + (wave & 3)];
+      issue(std::integral_constant<int, (P + PD - 1) % PD>{}, r1);
+    }
+    if (left > 0) {                           // the loads of the next batch are in flight meanwhile
+      pending_chunk(std::integral_constant<int, POS>{});
+      --left;
+    }
+    static_for<MB>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      constexpr int NW = (PD - 1) * MB * NF + (MB - 1 - j) * NF;
+      if constexpr (NF == 4) row_wait<NW>(xb[P][j][0], xb[P][j][1], xb[P][j][2], xb[P][j][3]);
+      else row_wait<NW>(xb[P][j][0], xb[P][j][1], xb[P][j][2]);
+    });
+    row_touch(ys);
+    const int fl = er[P][0] >> 27;            // has-padding, (south), first, last: of the batch on this side
+    if (fl & (CLS_FIRST << 1)) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) x0[f] = (double)xb[P][0][f];
+    }
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+      const double w = er[P][j] < 0 ? 0.0 : 1.0;   // (a padding entry: the whole row of this wave)
+      double dx[NF];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) dx[f] = (double)xb[P][j][f] - x0[f];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) s[f] += w * dx[f];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) q[k] += (w * dx[KD::pa(k)]) * dx[KD::pb(k)];
+      cnt += w;
+    }
+    if (fl & (CLS_LAST << 1)) {
+      if (left > 0)                           // (a side shorter than NCH steps: what is left of the previous projection)
+        static_for<NCH>([&](auto cc) __attribute__((always_inline)) {
+          if (((decltype(cc)::value - POS - 1) & (NCH - 1)) < left) pending_chunk(cc);
+        });
+      // ---- reading role: mean (theta = T x the column scale) and central co-moments of my class side
+      const double rcn = cnt > 0.0 ? temx_rcp_count(cnt) : 0.0;
+      double val[NV];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) val[f] = (s[f] * rcn + x0[f]) * (f == KD::TF ? sth : 1.0);
+#pragma unroll
+      for (int k = 0; k < NP; ++k) val[NF + k] = (q[k] - s[KD::pa(k)] * s[KD::pb(k)] * rcn) * (k == KD::TP ? sth : 1.0);
+      // every wave is done with the exchange area of the previous group (LDS reads retired, loads stay in flight)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      ycur ^= 1;
+      double* yw = ybase + ycur * YE;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) exw[v * 512] = val[v];
+      if (lane == 0) cn[wave] = cnt;
+      if (tid < YE) yw[tid] = ys;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      ++grp;
+      load_ys(grp);
+      // ---- tile role: class slot g, column c of d-tile tl; both sides of the class
+      double m2[2][NF], c2[2][NP];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        m2[0][f] = exr[f * 512];
+        m2[1][f] = exr[f * 512 + 256];
+      }
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        c2[0][k] = exr[(NF + k) * 512];
+        c2[1][k] = exr[(NF + k) * 512 + 256];
+      }
+      const double nN = cn[g], nS = cn[4 + g];
+      // reference at the class latitudes: E = even part, O = odd part; r_N = E + O, r_S = E - O
+      double E[NF], O[NF];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) E[f] = O[f] = 0.0;
+#pragma unroll
+      for (int tb = 0; tb < 2 * NBR; ++tb) {
+        const int blk = tb < NBR ? tb : TBX + (tb - NBR);
+        const double ya = yw[blk * 16 + aoff_r];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          if (tb < NBR)
+            E[f] = TEMX_MFMA4(ya, cb[(f * 2 * NBR + tb) * 64], E[f]);
+          else
+            O[f] = TEMX_MFMA4(ya, cb[(f * 2 * NBR + tb) * 64], O[f]);
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        m2[0][f] -= E[f] + O[f];              // side mean minus the reference
+        m2[1][f] -= E[f] - O[f];
+      }
+      const double sg = par ? -1.0 : 1.0;     // even harmonics: north + south; odd: north - south
+#pragma unroll
+      for (int f = 0; f < NFX; ++f) dS[f] = nN * m2[0][f] + sg * (nS * m2[1][f]);
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const double PNk = c2[0][k] + nN * m2[0][KD::pa(k)] * m2[0][KD::pb(k)];
+        const double PSk = c2[1][k] + nS * m2[1][KD::pa(k)] * m2[1][KD::pb(k)];
+        dP[k] = PNk + sg * PSk;
+      }
+      yprev = yw + par * (TBX * 16);
+      left = NCH;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) s[f] = 0.0;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) q[k] = 0.0;
+      cnt = 0.0;
+    }
+  };
+
+  if (b0 < b1) {
+    load_ys(grp);
+    rn = crow[(int64_t)b0 * 4 + (wave & 3)];
+    static_for<PD - 1>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int k = decltype(kc)::value;
+      const int4 r0 = rn;
+      rn = crow[(int64_t)(b0 + k + 1) * 4 + (wave & 3)];
+      issue(kc, r0);
+    });
+    constexpr int UNR = PD % 2 == 0 ? PD : 2 * PD;   // lcm(PD, NCH)
+    for (int b = b0; b < b1; b += UNR)
+      static_for<UNR>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        if (k == 0 || b + k < b1) step(kc, b + k);
+      });
+    // loads issued past b1 and the last Y prefetch are still landing in registers the compiler believes free
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (left > 0) {
+    const int first = (b1 - b0) & (NCH - 1);
+    static_for<NCH>([&](auto cc) __attribute__((always_inline)) {
+      if (((decltype(cc)::value - first) & (NCH - 1)) < left) pending_chunk(cc);
+    });
+  }
+  if (dvalid) {
+#pragma unroll
+    for (int f = 0; f < NFX; ++f)
+#pragma unroll
+      for (int t = 0; t < TBX; ++t) {
+        const int l = 2 * (4 * t + g) + par;  // block t of parity par, row g (symx_harm<TBX>(par * TBX + t, g))
+        if (l < KX) px[(((int64_t)split * NFX + f) * KX + l) * D + d] = ax[f][t];
+      }
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+#pragma unroll
+      for (int t = 0; t < TBS; ++t) {
+        const int l = 2 * (4 * t + g) + par;
+        if (l < K) pp[(((int64_t)split * NP + k) * K + l) * D + d] = apl[(k * TBS + t) * 64];
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Sweep 1 of the class-sum form with row-contiguous loads: sweep_op_kernel (kernels_op.hpp: same inputs, class-sum
 // records, partial slabs and arithmetic) read the way sweep_osr_kernel reads.  While it reads, wave w owns class
 // slot w of every class-group and the workgroup's 64 columns; at the end of a group it stores its class's sums

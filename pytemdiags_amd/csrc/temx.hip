@@ -21,6 +21,7 @@
 #include "kernels_cls.hpp"
 #include "kernels_op.hpp"
 #include "kernels_op2.hpp"
+#include "side_tables.hpp"
 
 using namespace temx;
 
@@ -137,6 +138,7 @@ struct temx_plan {
   std::vector<int> sgbatch0;           // subsample of class-groups (reference pre-pass): first batch of each (+ total)
   int64_t sgroups = 0, sbatches = 0;
   DevBuf ycx, ycx_s, crow_s, rho, rho0, gaunt /* Yq[NQ][KX] */, wq2, Gx, Gsinv, Ax, Axs, Pp;
+  DevBuf side_crow[2][2], side_gfirst[2][2];   // [full table, subsample][north, south]: side_tables.hpp (sweep_os2_kernel)
   std::map<int, DevBuf> csplits_s;
   Split sp_os, sp_os_s;
   Split sp_copw;                 // TEM + tracer in one sweep (sweep_opw_kernel<.., 2>): one d-tile per workgroup
@@ -1420,6 +1422,19 @@ static int build_os_tables(temx_plan* pl) {
       pl->sgroups = (int64_t)pl->sgbatch0.size();
       pl->sbatches = (int64_t)(crow_s.size() / (4 * CLS_MB));
       pl->sgbatch0.push_back((int)pl->sbatches);
+      {   // one row table per side, for the full table and for the subsample (sweep_os2_kernel: a wave per class side)
+        SideTables stb;
+        build_side_tables(pl->h_crow, pl->gbatch0, pl->cgroups, CLS_MB, CLS_PADB, CLS_SOUTH, CLS_FIRST, CLS_LAST, CLS_HASPAD_BIT, stb);
+        for (int sd = 0; sd < 2 && !rc; ++sd)
+          if (!(rc = upload(pl->side_crow[0][sd], stb.crow[sd].data(), stb.crow[sd].size() * sizeof(int))))
+            rc = upload(pl->side_gfirst[0][sd], stb.gfirst[sd].data(), stb.gfirst[sd].size() * sizeof(int));
+        std::vector<int> crow_full = crow_s;      // (not yet padded) + the terminating entry of sgbatch0
+        build_side_tables(crow_full, pl->sgbatch0, pl->sgroups, CLS_MB, CLS_PADB, CLS_SOUTH, CLS_FIRST, CLS_LAST, CLS_HASPAD_BIT, stb);
+        for (int sd = 0; sd < 2 && !rc; ++sd)
+          if (!(rc = upload(pl->side_crow[1][sd], stb.crow[sd].data(), stb.crow[sd].size() * sizeof(int))))
+            rc = upload(pl->side_gfirst[1][sd], stb.gfirst[sd].data(), stb.gfirst[sd].size() * sizeof(int));
+        if (rc) return rc;
+      }
       crow_s.resize(crow_s.size() + (size_t)CLS_PADB * 4 * CLS_MB, (int)0x80000000);
       xc_s.resize(xc_s.size() + 4, 0.0);
       DevBuf xs;
@@ -1541,8 +1556,19 @@ static int launch_sweep_os_t(temx_plan* pl, const FieldPtrs<4>& fp, bool sub, co
       hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->D, pl->K, pl->KX, sub ? pl->ycx_s.d() : pl->ycx.d(),   \
                          static_cast<const int4*>(sub ? pl->crow_s.p : pl->crow.p), cuts, pl->colscale.d(), rho,    \
                          pl->KR, px, pp, sp.nsplit, sp.ndt);                                                        \
+    } else if (sizeof(T) == 4) {   /* fp32 inputs: two waves per SIMD (kernels_op2.hpp, sweep_os2_kernel) */       \
+      auto kern = sweep_os2_kernel<float, TBSv, TBXv, NBR, 2, KIND>;                                                \
+      const size_t lds = ((size_t)2 * 2 * TBXv * 16 + 16 + (size_t)4 * KD::NF * 2 * NBR * 64 +                      \
+                          (size_t)8 * KD::NP * TBSv * 64 + (size_t)(KD::NF + KD::NP) * 512) * 8;                    \
+      static std::atomic<uint64_t> attr_set{0};                                                                     \
+      if (int rc_ = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(kern), (int)lds)) return rc_; \
+      const int si = sub ? 1 : 0;                                                                                   \
+      hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, fp, pl->D, pl->K, pl->KX, sub ? pl->ycx_s.d() : pl->ycx.d(), \
+                         static_cast<const int4*>(pl->side_crow[si][0].p), static_cast<const int4*>(pl->side_crow[si][1].p), \
+                         static_cast<const int*>(pl->side_gfirst[si][0].p), static_cast<const int*>(pl->side_gfirst[si][1].p), \
+                         cuts, pl->colscale.d(), rho, pl->KR, px, pp, sp.nsplit, sp.ndt);                           \
     } else {                                                                                                        \
-      auto kern = sweep_osr_kernel<T, TBSv, TBXv, NBR, 2, KIND>;                                                    \
+      auto kern = sweep_osr_kernel<double, TBSv, TBXv, NBR, 2, KIND>;                                               \
       const size_t lds = ((size_t)2 * 2 * TBXv * 16 + 16 + (size_t)4 * KD::NF * 2 * NBR * 64 +                      \
                           (size_t)4 * KD::NP * 2 * TBSv * 64 + (size_t)2 * (KD::NF + KD::NP) * 256) * 8;            \
       static std::atomic<uint64_t> attr_set{0};                                                                     \
@@ -1574,15 +1600,11 @@ static bool os_supported(const temx_plan* pl) {
   return (pl->TBS == 7 && tbx <= 13) || (pl->TBS == 4 && tbx <= 8) || (pl->TBS == 2 && tbx <= 4);
 }
 
-// the single-sweep forms run for fp64 inputs and for fp32 inputs with many columns per row (ne120 x 72 x 30 fp32:
-// 8.3-8.6 against 9.0-9.3 ms); fp32 rows of a few hundred bytes keep the class-sum forms (ne240 x 128 x 1: 2.2 against
-// 2.5 ms -- with fp32 inputs the sweep's arithmetic per point, not its bytes, is the limit) unless
-// TEMX_SINGLE_SWEEP=1 forces them
+// the single-sweep forms run for both input types (fp32 inputs take the two-waves-per-SIMD sweep);
+// TEMX_SINGLE_SWEEP=0 at plan build selects the class-sum forms
 static bool os_active(const temx_plan* pl, int dtype) {
-  if (!pl->os_on) return false;
-  if (dtype == TEMX_F64) return true;
-  const char* e = getenv("TEMX_SINGLE_SWEEP");
-  return (e && e[0] == '1') || pl->D >= 1024;
+  (void)dtype;
+  return pl->os_on;
 }
 
 static int tem_run_os(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, double* results, double* zonal, void* stream) {
@@ -1716,7 +1738,8 @@ void temx_plan_destroy(temx_plan* pl) {
   pl->pbuf.release();
   pl->gblk.release();
   pl->ypblk.release();
-  for (DevBuf* b : {&pl->T, &pl->Qp, &pl->GinvA, &pl->G2, &pl->xo, &pl->xc, &pl->ycx, &pl->ycx_s, &pl->crow_s, &pl->rho,
+  for (DevBuf* b : {&pl->T, &pl->Qp, &pl->GinvA, &pl->G2, &pl->xo, &pl->xc, &pl->ycx, &pl->ycx_s, &pl->crow_s, &pl->side_crow[0][0], &pl->side_crow[0][1], &pl->side_crow[1][0], &pl->side_crow[1][1],
+                    &pl->side_gfirst[0][0], &pl->side_gfirst[0][1], &pl->side_gfirst[1][0], &pl->side_gfirst[1][1], &pl->rho,
                     &pl->rho0, &pl->gaunt, &pl->wq2, &pl->Axq, &pl->Ppq, &pl->rho_t, &pl->Gx, &pl->Gsinv, &pl->Ax, &pl->Axs, &pl->Pp})
     b->release();
   for (auto& kv : pl->csplits_s) kv.second.release();

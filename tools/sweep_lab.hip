@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../pytemdiags_amd/csrc/kernels_op2.hpp"
+#include "../pytemdiags_amd/csrc/side_tables.hpp"
 
 using namespace temx;
 
@@ -225,6 +226,11 @@ int run(int64_t N, int64_t D, int reps, const char* only) {
   std::vector<int> crow, gb0, crow16_2, gb16_2, crow16_4, gb16_4;
   build_crow(cls, crow, gb0);
   if (!crow_file.empty()) { crow = crow_file; gb0 = gb0_file; }
+  if (getenv("LAB_PERMUTE")) {      // the same classes, but every row index sent through a random permutation of the rows:
+    for (auto& e : crow)            // is it the class structure or the addresses of the members that costs?
+      if (e >= 0) e = (e & ~CLS_ROWMASK) | perm[e & CLS_ROWMASK];
+    printf("LAB_PERMUTE: row indices of the table permuted\n");
+  }
   build_crow16(cls, 2, crow16_2, gb16_2);
   build_crow16(cls, 4, crow16_4, gb16_4);
   int* d_crow = to_dev(crow); int* d_crow16_2 = to_dev(crow16_2); int* d_crow16_4 = to_dev(crow16_4);
@@ -297,7 +303,8 @@ int run(int64_t N, int64_t D, int reps, const char* only) {
       std::vector<double> r((size_t)4 * K4r * D);
       for (auto& v : r) v = std::generate_canonical<double, 53>(gen) - 0.5;
       rho = to_dev(r);
-      os_px_n = (size_t)16 * 4 * KX * D; os_pp_n = (size_t)16 * 3 * K * D;
+      const size_t nsp = (size_t)std::max(16, choose_split(D, cunits, 256, 4, 8).nsplit);
+      os_px_n = nsp * 4 * KX * D; os_pp_n = nsp * 3 * K * D;
       CHK(hipMalloc(&px, os_px_n * 8));
       CHK(hipMalloc(&pp, os_pp_n * 8));
       CHK(hipMemset(px, 0, os_px_n * 8)); CHK(hipMemset(pp, 0, os_pp_n * 8));
@@ -328,6 +335,27 @@ int run(int64_t N, int64_t D, int reps, const char* only) {
         hipLaunchKernelGGL(kern, dim3(sp.grid), dim3(256), ldsb, 0, fp, D, K, KX, ycx_, reinterpret_cast<const int4*>(d_crow), cuts,
                            d_cs, rho_, K4r, px_, pp_, sp.nsplit, sp.ndt); }});
     };
+    static int *d_crowN = nullptr, *d_crowS = nullptr, *d_gfN = nullptr, *d_gfS = nullptr;
+    if (!d_crowN) {
+      SideTables stb;
+      build_side_tables(crow, gb0, ng, CLS_MB, CLS_PADB, CLS_SOUTH, CLS_FIRST, CLS_LAST, CLS_HASPAD_BIT, stb);
+      d_crowN = to_dev(stb.crow[0]); d_crowS = to_dev(stb.crow[1]); d_gfN = to_dev(stb.gfirst[0]); d_gfS = to_dev(stb.gfirst[1]);
+      printf("side tables: %d northern and %d southern batches\n", stb.gfirst[0].back(), stb.gfirst[1].back());
+    }
+    auto add_os2 = [&](auto nbrc, auto pdc) {
+      constexpr int NBR = decltype(nbrc)::value, PD = decltype(pdc)::value;
+      Split sp = choose_split(D, cunits, 256, 4, 8);
+      int2* cuts = reinterpret_cast<int2*>(to_dev(group_cuts(gb0, sp.nsplit)));
+      const size_t ldsb = ((size_t)2 * 2 * TBX * 16 + 16 + (size_t)4 * 4 * 2 * NBR * 64 + (size_t)8 * 3 * TBS * 64 + (size_t)7 * 512) * 8;
+      auto kern = sweep_os2_kernel<T, TBS, TBX, NBR, PD, 0>;
+      CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+      double *ycx_ = ycx, *rho_ = rho, *px_ = px, *pp_ = pp;
+      vars.push_back({"os2   ONE sweep, 2 waves per SIMD: a wave per class side reads, a wave per d-tile and parity projects, PD=" + std::to_string(PD), 0, [=](double*) {
+        hipLaunchKernelGGL(kern, dim3(sp.grid), dim3(512), ldsb, 0, fp, D, K, KX, ycx_, reinterpret_cast<const int4*>(d_crowN),
+                           reinterpret_cast<const int4*>(d_crowS), d_gfN, d_gfS, cuts, d_cs, rho_, K4r, px_, pp_, sp.nsplit, sp.ndt); }});
+    };
+    add_os2(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+    add_os2(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{});
     add_osr(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
     add_osr(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{});
     add_osr(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});     // (vmcnt counts to 63: 3 x 16 + 12 loads)
