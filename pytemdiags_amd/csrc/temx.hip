@@ -687,6 +687,37 @@ static bool build_classes(const double* lat, int64_t N, ClassTables& ct) {
     const int ar = a.n.empty() ? a.s[0] : a.n[0], br = b.n.empty() ? b.s[0] : b.n[0];
     return ar < br;
   });
+  // The class-groups (4 consecutive classes) of the few small strata -- ne240: 361 groups of 4 + 4 members and 90 of
+  // 8 + 0 behind 48 374 of 8 + 8 -- are spread evenly among the others: a work cut is a run of consecutive groups
+  // balanced by batch count, and the end of a group costs about as much as two batches, so the workgroup that got
+  // the tail of a size-sorted table ran 30 % longer than the rest (ne240 x 128 x 1: 1.9 instead of 1.5 ms;
+  // profiles/r03_lab20_class_order_d128_f32.log).  Inside a stratum the order stays.  A last, partial group stays last.
+  {
+    const size_t ngr = (cls.size() + 3) / 4;
+    std::vector<std::pair<int, int>> shape(ngr);
+    std::map<std::pair<int, int>, size_t> count, seen;
+    for (size_t gi = 0; gi < ngr; ++gi) {
+      int bN = 0, bS = 0;
+      for (size_t ci = gi * 4; ci < std::min(gi * 4 + 4, cls.size()); ++ci) {
+        bN = std::max(bN, nb(cls[ci].n.size()));
+        bS = std::max(bS, nb(cls[ci].s.size()));
+      }
+      shape[gi] = {bN, bS};
+      ++count[shape[gi]];
+    }
+    std::vector<std::pair<double, size_t>> key(ngr);
+    for (size_t gi = 0; gi < ngr; ++gi) {
+      const size_t i = seen[shape[gi]]++;
+      key[gi] = {((double)i + 0.5) / (double)count[shape[gi]], gi};
+      if (gi + 1 == ngr && cls.size() % 4 != 0) key[gi].first = 2.0;
+    }
+    std::stable_sort(key.begin(), key.end(), [](const std::pair<double, size_t>& a, const std::pair<double, size_t>& b) { return a.first < b.first; });
+    std::vector<Cls> out;
+    out.reserve(cls.size());
+    for (const auto& kv : key)
+      for (size_t ci = kv.second * 4; ci < std::min(kv.second * 4 + 4, cls.size()); ++ci) out.push_back(std::move(cls[ci]));
+    cls.swap(out);
+  }
   ct.ncls = (int64_t)cls.size();
   ct.ngroups = (ct.ncls + 3) / 4;
   ct.xc.assign((size_t)(ct.ngroups + 1) * 4, 0.0);
@@ -739,16 +770,25 @@ static bool build_classes(const double* lat, int64_t N, ClassTables& ct) {
 
 // (first batch, its group) of `nsub` pieces of the batch list: equal batch counts; a cut may fall
 // inside a class-group (the sweeps are linear in the member rows, the kernels project partial sums)
+#ifndef TEMX_GROUP_COST
+#define TEMX_GROUP_COST 2
+#endif
 static int class_cuts(temx_plan* pl, int nsub, const int2** out, bool group_aligned = false) {
   const int key = group_aligned ? -nsub : nsub;
   auto it = pl->csplits.find(key);
   if (it == pl->csplits.end()) {
     std::vector<int> cut((size_t)2 * (nsub + 1));
     int g = 0;
+    // group-aligned cuts balance batches + TEMX_GROUP_COST per class-group: the end of a group (exchange, reference,
+    // 100-160 MFMAs) costs about two batches, and the table ends with the small classes (ne240: 361 groups of 2
+    // batches), so that cuts by batch count alone gave the last workgroup twice the groups -- 1.9 instead of 1.5 ms
+    // for ne240 x 128 x 1 (profiles/r03_lab20_class_order_d128_f32.log)
+    const int64_t total = pl->cbatches + (int64_t)TEMX_GROUP_COST * pl->cgroups;
     for (int k = 0; k <= nsub; ++k) {
       const int64_t b = pl->cbatches * k / nsub;
       if (group_aligned) {     // the one-pass sweep stores whole-class sums: cut at the next group boundary
-        while (g < pl->cgroups && pl->gbatch0[(size_t)g] < b) ++g;
+        const int64_t want = total * k / nsub;
+        while (g < pl->cgroups && pl->gbatch0[(size_t)g] + (int64_t)TEMX_GROUP_COST * g < want) ++g;
         if (k == nsub) g = (int)pl->cgroups;
         cut[(size_t)2 * k] = pl->gbatch0[(size_t)g];
         cut[(size_t)2 * k + 1] = g;
@@ -1372,9 +1412,10 @@ static int os_cuts(temx_plan* pl, bool sub, int nsub, const int2** out) {
   if (it == pl->csplits_s.end()) {
     std::vector<int> cut((size_t)2 * (nsub + 1));
     int g = 0;
+    const int64_t total = pl->sbatches + (int64_t)TEMX_GROUP_COST * pl->sgroups;     // as class_cuts
     for (int k = 0; k <= nsub; ++k) {
-      const int64_t b = pl->sbatches * k / nsub;
-      while (g < pl->sgroups && pl->sgbatch0[(size_t)g] < b) ++g;
+      const int64_t want = total * k / nsub;
+      while (g < pl->sgroups && pl->sgbatch0[(size_t)g] + (int64_t)TEMX_GROUP_COST * g < want) ++g;
       if (k == nsub) g = (int)pl->sgroups;
       cut[(size_t)2 * k] = pl->sgbatch0[(size_t)g];
       cut[(size_t)2 * k + 1] = g;

@@ -109,9 +109,11 @@ static std::vector<int> group_cuts(const std::vector<int>& gbatch0, int nsub) {
   const int64_t ng = (int64_t)gbatch0.size() - 1, nbatch = gbatch0[ng];
   std::vector<int> cut(2 * (nsub + 1));
   int g = 0;
+  const int64_t gc = getenv("LAB_GROUP_COST") ? atoi(getenv("LAB_GROUP_COST")) : 2;   // batches a group end is worth (temx.hip: class_cuts)
+  const int64_t total = nbatch + gc * ng;
   for (int k = 0; k <= nsub; ++k) {
-    const int64_t b = nbatch * k / nsub;
-    while (g < ng && gbatch0[g] < b) ++g;
+    const int64_t want = total * k / nsub;
+    while (g < ng && gbatch0[g] + gc * g < want) ++g;
     if (k == nsub) g = (int)ng;
     cut[2 * k] = gbatch0[g]; cut[2 * k + 1] = g;
   }
