@@ -278,7 +278,7 @@ def main():
                                "ten GM16 Table-A1 outputs" % (ne, ncol, nlev, nt, "GPU" if scaling == "weak" else "job"),
                    "shard": args.shard if (world > 1 or use_ncol) else "none", "ncol": int(ncol), "nlev": nlev, "nt": nt,
                    "sweeps": ("generic", "mirror-paired", "latitude-class")[plan.sweep_mode]
-                             + (", single sweep" if (getattr(plan, "single_sweep", False) and args.dtype == "f64")
+                             + (", single sweep" if getattr(plan, "single_sweep", False)
                                 else (", one pass" if plan.one_pass else "")),
                    "mirror_paired_sweeps": bool(plan.paired)},
         # per-step HIP-event times of the same K steps (this rank): SURVEY 8(d) quotes the median of >= 20
@@ -305,7 +305,7 @@ def main():
         if plan.one_pass and nproj:
             # one-pass class path: the dominant kernel is sweep 1 (the only read of the fields)
             gbs_p = 4 * esize * pts_rank / (proj_ms * 1e-3) / 1e9
-            single = bool(getattr(plan, "single_sweep", False)) and (args.dtype == "f64" or nlev * nt >= 1024)   # (short fp32 rows keep the class-sum form)
+            single = bool(getattr(plan, "single_sweep", False))
             rec["roofline"] = {"kernel": ("sweep_osr_kernel (the single sweep, loads of 1 row x 64 columns: theta, class sums of the four fields minus a low-degree "
                                           "reference projected to degree 2L, their three products to degree L; no class-sum stream)"
                                           if single else
@@ -412,7 +412,7 @@ def main():
                     "ms_per_step": dt2 * 1e3, "grid_points_per_s": pts2 / dt2, "reps": reps, "ncol": int(lat2.size),
                     "plan_symmetry": not generic,
                     "sweeps": ("generic", "mirror-paired", "latitude-class")[p2.sweep_mode]
-                              + (", single sweep" if (getattr(p2, "single_sweep", False) and dt2_t == torch.float64)
+                              + (", single sweep" if getattr(p2, "single_sweep", False)
                                  else (", one pass" if p2.one_pass else "")),
                     "frac_of_fp64_roofline": pts2 / dt2 / (PEAK_F64_TFLOPS * 1e12 / FLOPS_PER_PT)}
                 p2.close()

@@ -166,7 +166,7 @@ int temx_plan_one_pass(const temx_plan* plan);
  * such a temx_tem_run takes the tracer's own single sweep over (q, v, omega): it reuses the projections and
  * references of v and omega the TEM run left in the plan -- the SAME va, wap must be handed over, as for the
  * one-pass tracer stages -- and any temx_tem_stage1 / temx_plan_set_tem in between sends it back to the other
- * forms.  fp32 inputs take the single sweep from 1024 columns (D = nlev * nt) up and the class-sum forms below. */
+ * forms.  Both input types take it (fp32 inputs with a two-waves-per-SIMD variant of the sweep). */
 int temx_plan_single_sweep(const temx_plan* plan);
 
 int temx_get_matrix(temx_plan* plan, int which, double* dst, void* stream);
