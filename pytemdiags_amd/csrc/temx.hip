@@ -1450,7 +1450,10 @@ static int build_os_tables(temx_plan* pl) {
       hipLaunchKernelGGL(cls_basis_kernel<512>, dim3((unsigned)((pl->cls_npad + 255) / 256)), dim3(256), 0, 0, pl->xc.d(),
                          pl->ncls, pl->cls_npad, KX, TBX, nd.d(), (const double*)nullptr, pl->ycx.d());
       // subsample of class-groups for the reference fit: every S-th group, its batches copied
-      const int64_t S = std::max<int64_t>(1, std::min<int64_t>(64, pl->cgroups / 192));
+      // (about 100 class-groups = 400 latitudes for the 16 coefficients of a column; env TEMX_OS_SUBSAMPLE: groups kept)
+      const char* ess = getenv("TEMX_OS_SUBSAMPLE");
+      const int64_t keep = ess ? std::max(16, atoi(ess)) : 96;
+      const int64_t S = std::max<int64_t>(1, std::min<int64_t>(256, pl->cgroups / keep));
       std::vector<int> crow_s;
       std::vector<double> xc_s;
       pl->sgbatch0.clear();
@@ -2424,7 +2427,8 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
             }
             if (want) {
               pl->sp_os = choose_split(D, cunits, pl->num_cu, 4, 8);
-              pl->sp_os_s = choose_split(D, std::max<int64_t>(1, pl->sbatches / 4), pl->num_cu, 4, 2);
+              // (one round of workgroups: the pre-pass is all prologue and epilogue)
+              pl->sp_os_s = choose_split(D, std::max<int64_t>(1, pl->sbatches / 4), std::max(1, pl->num_cu / 2), 4, 2);
               const size_t per = ((size_t)4 * pl->KX + 3 * pl->K) * D * 8;
               if ((rc = pl->partial.ensure(std::max((size_t)std::max(pl->sp_os.nsplit, pl->sp_os_s.nsplit) * per, pl->partial.bytes)))) return rc;
               if ((rc = pl->Ax.ensure((size_t)4 * pl->KX * D * 8))) return rc;

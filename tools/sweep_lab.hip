@@ -277,7 +277,7 @@ int run(int64_t N, int64_t D, int reps, const char* only) {
   std::vector<Variant> vars;
   const int64_t cunits = std::max<int64_t>(1, gb0[ng] / 4);
   {   // reference: one wave per SIMD, quads of d-tiles
-    Split sp = choose_split(D, cunits, 256, 4, 8);
+    Split sp = choose_split(D, cunits, getenv("LAB_SLOTS") ? atoi(getenv("LAB_SLOTS")) : 256, 4, 8);
     int2* cuts = reinterpret_cast<int2*>(to_dev(group_cuts(gb0, sp.nsplit)));
     vars.push_back({"op    8B loads, 98 acc, 1 wave/SIMD (library)", sp.nsplit, [=](double* cs_out) {
       hipLaunchKernelGGL((sweep_op_kernel<T, TBS, sizeof(T) == 8 ? 3 : 6, 0>), dim3(sp.grid), dim3(256), 0, 0, fp, D, K, d_ycls,
@@ -305,7 +305,7 @@ int run(int64_t N, int64_t D, int reps, const char* only) {
       std::vector<double> r((size_t)4 * K4r * D);
       for (auto& v : r) v = std::generate_canonical<double, 53>(gen) - 0.5;
       rho = to_dev(r);
-      const size_t nsp = (size_t)std::max(16, choose_split(D, cunits, 256, 4, 8).nsplit);
+      const size_t nsp = (size_t)std::max(16, choose_split(D, cunits, getenv("LAB_SLOTS") ? atoi(getenv("LAB_SLOTS")) : 256, 4, 8).nsplit);
       os_px_n = nsp * 4 * KX * D; os_pp_n = nsp * 3 * K * D;
       CHK(hipMalloc(&px, os_px_n * 8));
       CHK(hipMalloc(&pp, os_pp_n * 8));
@@ -314,7 +314,7 @@ int run(int64_t N, int64_t D, int reps, const char* only) {
     auto add_os = [&](auto nbrc, auto pdc, auto dfc) {
       constexpr int NBR = decltype(nbrc)::value, PD = decltype(pdc)::value;
       constexpr int DF = decltype(dfc)::value;
-      Split sp = choose_split(D, cunits, 256, 4, 8);
+      Split sp = choose_split(D, cunits, getenv("LAB_SLOTS") ? atoi(getenv("LAB_SLOTS")) : 256, 4, 8);
       int2* cuts = reinterpret_cast<int2*>(to_dev(group_cuts(gb0, sp.nsplit)));
       const size_t ldsb = ((size_t)4 * (DF ? 2 : 1) * 2 * TBX * 16 + (size_t)4 * 4 * 2 * NBR * 64 + (size_t)4 * 3 * 2 * TBS * 64) * 8;
       auto kern = sweep_os_kernel<T, TBS, TBX, NBR, PD, 0, DF>;
@@ -327,7 +327,7 @@ int run(int64_t N, int64_t D, int reps, const char* only) {
     };
     auto add_osr = [&](auto nbrc, auto pdc) {
       constexpr int NBR = decltype(nbrc)::value, PD = decltype(pdc)::value;
-      Split sp = choose_split(D, cunits, 256, 4, 8);
+      Split sp = choose_split(D, cunits, getenv("LAB_SLOTS") ? atoi(getenv("LAB_SLOTS")) : 256, 4, 8);
       int2* cuts = reinterpret_cast<int2*>(to_dev(group_cuts(gb0, sp.nsplit)));
       const size_t ldsb = ((size_t)2 * 2 * TBX * 16 + 16 + (size_t)4 * 4 * 2 * NBR * 64 + (size_t)4 * 3 * 2 * TBS * 64 + (size_t)14 * 256) * 8;
       auto kern = sweep_osr_kernel<T, TBS, TBX, NBR, PD, 0>;
@@ -346,7 +346,7 @@ int run(int64_t N, int64_t D, int reps, const char* only) {
     }
     auto add_os2 = [&](auto nbrc, auto pdc) {
       constexpr int NBR = decltype(nbrc)::value, PD = decltype(pdc)::value;
-      Split sp = choose_split(D, cunits, 256, 4, 8);
+      Split sp = choose_split(D, cunits, getenv("LAB_SLOTS") ? atoi(getenv("LAB_SLOTS")) : 256, 4, 8);
       int2* cuts = reinterpret_cast<int2*>(to_dev(group_cuts(gb0, sp.nsplit)));
       const size_t ldsb = ((size_t)2 * 2 * TBX * 16 + 16 + (size_t)4 * 4 * 2 * NBR * 64 + (size_t)8 * 3 * TBS * 64 + (size_t)7 * 512) * 8;
       auto kern = sweep_os2_kernel<T, TBS, TBX, NBR, PD, 0>;
