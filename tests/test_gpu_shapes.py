@@ -781,3 +781,55 @@ def test_row_map_sweeps_equal_tile_map_sweeps(monkeypatch, ne, nlev, nt, dtype):
         for i in range(a.shape[0]):
             scale = float(b[i].abs().max())
             assert float((a[i] - b[i]).abs().max()) <= 1e-11 * scale, (what, i)
+
+
+@pytest.mark.parametrize("dtype,single", [(np.float64, True), (np.float32, True), (np.float64, False)])
+def test_row_map_kernels_on_uneven_classes(monkeypatch, dtype, single):
+    """The sweeps of DESIGN.md 5d (sweep_osr_kernel for fp64, sweep_os2_kernel for fp32 inputs, sweep_opr_kernel for
+    the class-sum form) on a grid with uneven class sizes, classes on one hemisphere only, padding rows, groups
+    without a southern (or northern) batch -- against the oracle, TEM and tracer."""
+    from oracle import tem_oracle as orc
+    from pytemdiags_amd import _lib, engine, synth
+    import os
+    if any(os.environ.get(k) == "1" for k in ("TEMX_NO_SYM", "TEMX_NO_CLS", "TEMX_TWO_PASS", "TEMX_NO_QR")):
+        pytest.skip("needs the one-pass class path on the re-orthogonalised basis")
+    rng = np.random.default_rng(23)
+    lats = []
+    for a in np.concatenate([[0.0, 90.0], rng.uniform(0.5, 89.5, 900)]):
+        nn, ns = rng.integers(0, 12, 2)
+        if single:                 # the single sweep needs the re-orthogonalised basis, which keeps the parity of the
+            ns = nn = max(nn, 1)   # harmonics only on a mirror-symmetric grid: uneven sizes, but the same on both sides
+        if nn + ns == 0:
+            nn = 3
+        if a == 0.0:
+            nn, ns = nn + ns, 0    # (the equator class: northern batches only)
+        lats += [a] * nn + [-a] * ns
+    lat = np.array(lats)
+    rng.shuffle(lat)
+    lon = rng.uniform(0, 360, lat.size)
+    nlev, nt, L = 16, 12, 30                                  # D = 192: three full workgroup columns
+    plev = synth.pressure_levels(nlev)
+    f = synth.analytic_fields(lat, lon, plev, nt, seed=6, dtype=dtype)
+    q = synth.analytic_tracer(lat, lon, plev, nt).astype(dtype)
+    ref = orc.TEMOracle(*f, lat, plev, L=L, mode="factorised", q=[q])
+    monkeypatch.setenv("TEMX_ONE_PASS", "1")
+    monkeypatch.setenv("TEMX_SINGLE_SWEEP", "1" if single else "0")
+    plan = engine.Plan(lat, ref.lat, L)
+    plan.set_tem(nlev, nt, plev * 100)
+    assert plan.one_pass and plan.single_sweep == single
+    d = [torch.as_tensor(x, device="cuda:0") for x in f]
+    dq = torch.as_tensor(q, device="cuda:0")
+    tol = 1e-10 if dtype == np.float64 else 2e-5
+    res, zon = plan.tem_run(*d, want_zonal=True)
+    tres, _ = plan.tracer_run(dq, d[1], d[3])
+    assert not plan.status()
+    for i, n in enumerate(_lib.RESULT_NAMES):
+        e = fieldnorm_err(res[i].cpu().numpy(), getattr(ref, n)())
+        assert e <= tol, (n, e)
+    for i, n in enumerate(_lib.ZONAL_NAMES):
+        e = fieldnorm_err(zon[i].cpu().numpy(), getattr(ref, n))
+        assert e <= tol, (n, e)
+    for k, n in enumerate(_lib.TRACER_RESULT_NAMES):
+        e = fieldnorm_err(tres[k].cpu().numpy(), getattr(ref, n)(0))
+        assert e <= tol, (n, e)
+    plan.close()
