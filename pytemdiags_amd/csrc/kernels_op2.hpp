@@ -1142,15 +1142,18 @@ sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restr
 // VALU add per load whose result registers it takes from the batch still in flight, so the issue waits for that
 // batch -- or mixes both forms under SGPR pressure.  Issued by hand the loads are invisible to its wait-count
 // pass: row_wait<N>() is the s_waitcnt that makes the named values usable (N = loads issued after them).
+#ifndef TEMX_ROWLOAD_MOD
+#define TEMX_ROWLOAD_MOD "nt"     // cache policy of the row loads (lab A/B: "", "sc1", "sc0 sc1" -- all 8.85-9.02 ms, no difference)
+#endif
 template <typename T> struct RowLoad;
 template <> struct RowLoad<double> {
   static __device__ __forceinline__ void ld(double& dst, uint32_t voff, uint64_t sbase) {
-    asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, %2 " TEMX_ROWLOAD_MOD : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
   }
 };
 template <> struct RowLoad<float> {
   static __device__ __forceinline__ void ld(float& dst, uint32_t voff, uint64_t sbase) {
-    asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+    asm volatile("global_load_dword %0, %1, %2 " TEMX_ROWLOAD_MOD : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
   }
 };
 // 1 / n for a member count n (a small positive integer): v_rcp_f64 and one Newton step instead of the division's
