@@ -1477,12 +1477,11 @@ static int build_os_tables(temx_plan* pl) {
         for (int sd = 0; sd < 2 && !rc; ++sd)
           if (!(rc = upload(pl->side_crow[1][sd], stb.crow[sd].data(), stb.crow[sd].size() * sizeof(int))))
             rc = upload(pl->side_gfirst[1][sd], stb.gfirst[sd].data(), stb.gfirst[sd].size() * sizeof(int));
-        if (rc) return rc;
       }
       crow_s.resize(crow_s.size() + (size_t)CLS_PADB * 4 * CLS_MB, (int)0x80000000);
       xc_s.resize(xc_s.size() + 4, 0.0);
       DevBuf xs;
-      if (!(rc = upload(pl->crow_s, crow_s.data(), crow_s.size() * sizeof(int))) && !(rc = upload(xs, xc_s.data(), xc_s.size() * 8)) &&
+      if (!rc && !(rc = upload(pl->crow_s, crow_s.data(), crow_s.size() * sizeof(int))) && !(rc = upload(xs, xc_s.data(), xc_s.size() * 8)) &&
           !(rc = pl->ycx_s.ensure((size_t)(pl->sgroups + 1) * 2 * TBX * 16 * 8))) {
         const int64_t np = (pl->sgroups + 1) * 4;
         // classes beyond the real ones in the last group of the full table have count 0 and x = 0: harmless rows
