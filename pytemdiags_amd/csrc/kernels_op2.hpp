@@ -28,6 +28,13 @@
 //
 //  * parity pair with redundant loads (sweep_opp_kernel, VERDICT r02's option (a)): 48.8 ms.  Loads served
 //    by L1 / L2 instead of HBM are far from free at this rate.
+//
+// Second half of round 3 -- the kernels the library runs by default are further down in this file:
+//  * the single sweep: sweep_os_kernel (tile-shaped loads; A/B), os_ref_solve_kernel,
+//    os_contract_kernel;
+//  * the sweeps that load 1 row x 64 columns per instruction: RowLoad / row_wait (hand-issued
+//    loads), sweep_osr_kernel (single sweep, fp64 inputs), sweep_os2_kernel (single sweep with two waves per SIMD,
+//    fp32 inputs; row tables per side from side_tables.hpp), sweep_opr_kernel (sweep 1 of the class-sum form, fp64).
 #pragma once
 #include "kernels_op.hpp"
 
