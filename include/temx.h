@@ -47,7 +47,33 @@ enum {
 enum {
   TEMX_DEFER_FINALIZE = 1,
   TEMX_NO_SYMMETRY = 2,  /* generic sweeps only: neither latitude classes nor mirror pairing */
-  TEMX_NO_CLASSES = 4    /* do not use the latitude-class sweeps (mirror pairing is still tried) */
+  TEMX_NO_CLASSES = 4,   /* do not use the latitude-class sweeps (mirror pairing is still tried) */
+  TEMX_NO_QR = 8         /* keep the Y0 basis and the explicit inverse of the normal equations (A/B runs; see
+                            temx_plan_finalize).  TEMX_NO_QR=0/1 in the environment overrides */
+};
+
+/* Path selection (temx_plan_configure; takes effect at the next temx_plan_set_tem, which must follow).  The
+ * defaults choose by grid and problem size; the TEMX_* environment variables named here override both. */
+enum {
+  TEMX_OPT_FORM = 1,               /* form of the latitude-class sweeps, TEMX_FORM_*
+                                      (env: TEMX_TWO_PASS=1, TEMX_ONE_PASS=1, TEMX_SINGLE_SWEEP=0/1) */
+  TEMX_OPT_OS_MAP = 2,             /* single sweep: 0 loads of 1 row x 64 columns (default), 1 the MFMA tile of
+                                      4 rows x 16 columns (env: TEMX_OS_MAP=tile) */
+  TEMX_OPT_OP_MAP = 3,             /* the same for sweep 1 of the class-sum form (env: TEMX_OP_MAP=tile) */
+  TEMX_OPT_OS_SUBSAMPLE = 4,       /* class-groups of this plan's rows that enter the reference fit of the single
+                                      sweep (default 96; an ncol-sharded job wants about 96 / ranks per rank; set
+                                      before temx_plan_set_tem builds the tables; env: TEMX_OS_SUBSAMPLE) */
+  TEMX_OPT_TRACER_ONE_PASS = 5,    /* temx_tracer_run on the class-sum form: 1 = one-pass tracer stages
+                                      (env: TEMX_TRACER_ONE_PASS=1) */
+  TEMX_OPT_SINGLE_SWEEP_MIN_GROUPS = 6 /* smallest number of class-groups for which the automatic choice takes the
+                                      single sweep (default 2048) */
+};
+enum {
+  TEMX_FORM_AUTO = -1,
+  TEMX_FORM_TWO_PASS = 0,          /* fields read twice (project sweep, eddy sweep) */
+  TEMX_FORM_CLASS_SUMS = 1,        /* one pass with per-class sums + flux kernel wherever possible, never the single sweep */
+  TEMX_FORM_SINGLE_SWEEP = 2,      /* the single sweep wherever its instantiations exist */
+  TEMX_FORM_NO_SINGLE_SWEEP = 3    /* automatic choice between the two forms above by problem size, never the single sweep */
 };
 
 /* which matrix temx_get_matrix copies */
@@ -57,8 +83,12 @@ enum {
   TEMX_MAT_GRAM = 2,  /* [K][K]   Y0^T Y0 (this rank's rows only until finalised with a global G) */
   TEMX_MAT_GINV = 3,  /* [K][K]   inverse Gram; Y0inv = GINV . Y0^T */
   TEMX_MAT_Y0INV = 4, /* [K][N]   pinv(Y0) as the reference stores it, sph_zonal_mean.py:389 */
-  TEMX_MAT_GRAM2 = 5  /* [K][K]   Q^T Q over this rank's rows, Q = Y0 R^-1 the basis the finalised plan projects
+  TEMX_MAT_GRAM2 = 5, /* [K][K]   Q^T Q over this rank's rows, Q = Y0 R^-1 the basis the finalised plan projects
                                   on (see temx_plan_finalize); the identity if the plan keeps the Y0 basis */
+  TEMX_MAT_GX = 6,    /* [K][2L+1] Y0^T Y0ext over this rank's rows, Y0ext = Y_l^0 up to degree 2L (single sweep;
+                                  after temx_plan_set_tem on a plan with temx_plan_single_sweep() == 1) */
+  TEMX_MAT_GSUB = 7   /* [KR][KR] Gram matrix of the first KR = min(16, K) harmonics over this rank's share of the
+                                  reference subsample (single sweep) */
 };
 
 /* order of the ten GM16 Table-A1 results in the results buffer (tem_diagnostics.py:1018-1022) */
@@ -171,6 +201,16 @@ int temx_plan_single_sweep(const temx_plan* plan);
 
 int temx_get_matrix(temx_plan* plan, int which, double* dst, void* stream);
 
+/* Path selection, see TEMX_OPT_*.  temx_plan_option returns the value in effect (for TEMX_OPT_FORM: the form
+ * the configured plan runs, a TEMX_FORM_* value), -1 for an unknown option. */
+int temx_plan_configure(temx_plan* plan, int option, int value);
+int temx_plan_option(const temx_plan* plan, int option);
+
+/* ncol-sharded single sweep: every rank hands back the all-reduced TEMX_MAT_GX and TEMX_MAT_GSUB (host
+ * pointers) after temx_plan_set_tem; until then a plan that was finalised with an external Gram matrix and whose
+ * own subsample cannot be fitted refuses to run (TEMX_ESTATE). */
+int temx_plan_set_os_matrices(temx_plan* plan, const double* Gx_host /* [K][2L+1] */, const double* Gsub_host /* [KR][KR] */);
+
 /* ---- operator API: replaces _sph_zonal_mean_generic (sph_zonal_mean.py:187-283) ------------ */
 
 /* B[K][D] = Q^T A  (this rank's columns; raw sums in the plan's projection basis, Q = Y0 R^-1 after
@@ -222,6 +262,46 @@ int temx_tem_stage3(temx_plan* plan, const double* B3, double* results, double* 
  * form when the plan runs the one-pass class path. */
 int temx_tem_run(temx_plan* plan, const void* ua, const void* va, const void* ta,
                  const void* wap, int dtype, double* results, double* zonal, void* stream);
+
+/* ---- the single sweep in three steps: the ncol-sharded form of temx_tem_run -------------------------------
+ * (temx_plan_single_sweep(plan) == 1).  Every step of the pipeline after the zonal sums -- solve, product
+ * linearisation, vertical stencils, epilogue (tem_diagnostics.py:574-797) -- acts along latitude and pressure only,
+ * i.e. independently per time snapshot, and the sums are linear in the rows (sph_zonal_mean.py:251).  So an ncol-sharded job
+ * exchanges the sums by a REDUCE-SCATTER OVER TIME and every rank finishes the snapshots it receives: nothing of the
+ * tail is replicated, the results stay time-sharded.  Per step and rank:
+ *   temx_tem_os_prepass  As[4][KR][D] = raw sums of the four fields over the rank's share of the reference
+ *                        subsample, first KR = min(16, L+1) harmonics         -> all-reduce (4 KR D doubles)
+ *   temx_tem_os_sweep    reference coefficients from As, the ONE sweep over the rank's columns, and its reduction:
+ *                        proj = (4 (2L+1) + 3 (L+1)) rows of projections, written as nslices time slices
+ *                        [nslices][rows][nlev][ceil(nt / nslices)] (slice w holds the snapshots of
+ *                        shard_bounds(nt, nslices, w), rows of nlev x ntw(w) columns packed at its start;
+ *                        nslices == 1: [rows][nlev][nt])                      -> reduce-scatter (one slice per rank)
+ *   temx_tem_os_tail     proj_slice [rows][nlev][nts] for the snapshots [t0, t0 + nts): the ten results
+ *                        [TEMX_NRESULTS][M][nlev][nts] (and the zonal intermediates) for those snapshots.
+ * temx_tem_run on such a plan is the three calls with nslices = 1.  After a tail on a proper slice the plan's
+ * coefficients describe that slice only: the staged entry points for the whole run (temx_tem_stage3,
+ * temx_tracer_stage2 ..., temx_tem_eddy) return TEMX_ESTATE until a whole-run stage 1 / 2 has run again.
+ * The tracer (after temx_tem_os_tail on the same snapshots, same va / wap): temx_tracer_os_prepass (Asq[KR][D],
+ * all-reduce), temx_tracer_os_sweep (projq: (2L+1) + 2 (L+1) rows, sliced like proj), temx_tracer_os_tail. */
+int temx_tem_os_prepass(temx_plan* plan, const void* ua, const void* va, const void* ta, const void* wap, int dtype,
+                        double* As, void* stream);
+int temx_tem_os_sweep(temx_plan* plan, const void* ua, const void* va, const void* ta, const void* wap, int dtype,
+                      const double* As, int nslices, double* proj, void* stream);
+int temx_tem_os_tail(temx_plan* plan, const double* proj_slice, int64_t t0, int64_t nts, double* results,
+                     double* zonal, void* stream);
+int temx_tracer_os_prepass(temx_plan* plan, const void* q, const void* va, const void* wap, int dtype, double* Asq,
+                           void* stream);
+int temx_tracer_os_sweep(temx_plan* plan, const void* q, const void* va, const void* wap, int dtype,
+                         const double* Asq, int nslices, double* projq, void* stream);
+int temx_tracer_os_tail(temx_plan* plan, const double* projq_slice, double* tres, double* tzon, void* stream);
+
+/* The same time-sliced tail for raw sums of ANY form of the sweeps (class-sum form, paired, generic):
+ * B4s [4][K][nlev][nts] and B3s [3][K][nlev][nts] (summed over the ranks) -> stages 2b + 3 for the snapshots
+ * [t0, t0 + nts).  temx_time_slices cuts whole arrays of `rows` rows x [nlev][nt] into the reduce-scatter layout
+ * described above. */
+int temx_tem_tail_from_sums(temx_plan* plan, const double* B4s, const double* B3s, int64_t t0, int64_t nts,
+                            double* results, double* zonal, void* stream);
+int temx_time_slices(temx_plan* plan, const double* B, int64_t rows, int nslices, double* out, void* stream);
 
 /* lazily materialise the native-grid eddy fields (properties up vp thetap wapp upvp upwapp vptp,
  * tem_diagnostics.py:420-433).  Needs the coefficients of a previous stage2/run on this plan.

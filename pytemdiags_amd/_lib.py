@@ -11,12 +11,18 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TEMX_LIB") or os.path.join(_HERE, "libtemx.so")   # TEMX_LIB: A/B builds
 
-ABI_VERSION = 300           # temx_version() of the library these bindings were written for (include/temx.h)
+ABI_VERSION = 400           # temx_version() of the library these bindings were written for (include/temx.h)
 F64, F32 = 0, 1
 DEFER_FINALIZE = 1
 NO_SYMMETRY = 2
 NO_CLASSES = 4
-MAT_Y0, MAT_Y0P, MAT_GRAM, MAT_GINV, MAT_Y0INV, MAT_GRAM2 = 0, 1, 2, 3, 4, 5
+NO_QR = 8
+MAT_Y0, MAT_Y0P, MAT_GRAM, MAT_GINV, MAT_Y0INV, MAT_GRAM2, MAT_GX, MAT_GSUB = 0, 1, 2, 3, 4, 5, 6, 7
+# temx_plan_configure options and the forms of the latitude-class sweeps (include/temx.h)
+OPT_FORM, OPT_OS_MAP, OPT_OP_MAP, OPT_OS_SUBSAMPLE, OPT_TRACER_ONE_PASS, OPT_SINGLE_SWEEP_MIN_GROUPS = 1, 2, 3, 4, 5, 6
+FORM_AUTO, FORM_TWO_PASS, FORM_CLASS_SUMS, FORM_SINGLE_SWEEP, FORM_NO_SINGLE_SWEEP = -1, 0, 1, 2, 3
+FORMS = {"auto": FORM_AUTO, "two-pass": FORM_TWO_PASS, "class-sums": FORM_CLASS_SUMS,
+         "single-sweep": FORM_SINGLE_SWEEP, "no-single-sweep": FORM_NO_SINGLE_SWEEP}
 
 RESULT_NAMES = ("vtem", "omegatem", "wtem", "psitem", "epfy", "epfz", "epdiv",
                 "utendepfd", "utendvtem", "utendwtem")
@@ -47,6 +53,9 @@ SIGNATURES = [
     ("temx_plan_one_pass", _i, [_vp]),
     ("temx_plan_single_sweep", _i, [_vp]),
     ("temx_get_matrix", _i, [_vp, _i, _vp, _vp]),
+    ("temx_plan_configure", _i, [_vp, _i, _i]),
+    ("temx_plan_option", _i, [_vp, _i]),
+    ("temx_plan_set_os_matrices", _i, [_vp, _dp, _dp]),
     ("temx_project", _i, [_vp, _vp, _i, _i64, _vp, _vp]),
     ("temx_zonal_mean", _i, [_vp, _vp, _i, _i64, _vp, _i, _vp]),
     ("temx_zonal_mean_from_sums", _i, [_vp, _vp, _i64, _vp, _i, _vp]),
@@ -56,6 +65,14 @@ SIGNATURES = [
     ("temx_tem_stage2_from_sums", _i, [_vp, _vp, _vp, _vp]),
     ("temx_tem_stage3", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("temx_tem_run", _i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    ("temx_tem_os_prepass", _i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    ("temx_tem_os_sweep", _i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    ("temx_tem_os_tail", _i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    ("temx_tracer_os_prepass", _i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    ("temx_tracer_os_sweep", _i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    ("temx_tracer_os_tail", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("temx_tem_tail_from_sums", _i, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    ("temx_time_slices", _i, [_vp, _vp, _i64, _i, _vp, _vp]),
     ("temx_tem_eddy", _i, [_vp, _vp, _vp, _vp, _vp, _i, C.POINTER(_vp), _vp]),
     ("temx_tem_eddy_rows", _i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i64, C.POINTER(_vp), _vp]),
     ("temx_tracer_stage1", _i, [_vp, _vp, _i, _vp, _vp]),

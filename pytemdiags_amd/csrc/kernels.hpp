@@ -286,9 +286,35 @@ project_kernel(FieldPtrs<NF> fp, int64_t N, int64_t D, int K, const double* __re
 // sums its splits in ascending order, the 16 lane sums are combined in a fixed order.
 // Slab sp starts at partial + sp * stride (stride >= n: a sweep may interleave other slabs);
 // `addend` (NULL or [n]) is added last.
+//
+// Where the sum of entry idx goes.  The entries are rows of [nlev][nt] columns (time fastest).  An ncol-sharded job
+// exchanges them by a reduce-scatter over TIME -- everything after the zonal sums (solve, contraction, vertical
+// stencils, epilogue; tem_diagnostics.py:574-797) acts along latitude and pressure only, so a rank can finish the
+// snapshots it receives on its own.  The reduction therefore writes the layout the collective wants,
+//   out[w][row0 + row][lev][t - t0(w)],   chunk w = `chunk` doubles, rows of nlev x ntw(w) columns inside it,
+// the snapshots cut like sharding.shard_bounds (the first nt % W ranks hold one more).  D == 0: out[idx] (no map).
+struct SliceMap {
+  int64_t D = 0;       // columns per row (nlev * nt); 0 = identity
+  int nt = 1, W = 1;   // snapshots, slices
+  int64_t chunk = 0;   // doubles per slice of the output
+  int64_t row0 = 0;    // first row of this reduction inside a slice
+};
+__device__ __forceinline__ int64_t slice_index(const SliceMap& m, int64_t idx) {
+  if (m.D == 0) return idx;
+  const int64_t row = idx / m.D, d = idx - row * m.D;
+  const int lev = (int)(d / m.nt), t = (int)(d - (int64_t)lev * m.nt);
+  const int base = m.nt / m.W, extra = m.nt - base * m.W, tb = extra * (base + 1);
+  int w, tl, ntw;
+  if (t < tb) { w = t / (base + 1); tl = t - w * (base + 1); ntw = base + 1; }
+  else { const int u = t - tb; w = extra + u / base; tl = u - (w - extra) * base; ntw = base; }
+  const int nlev = (int)(m.D / m.nt);
+  return (int64_t)w * m.chunk + ((m.row0 + row) * nlev + lev) * ntw + tl;
+}
+
 __global__ void __launch_bounds__(256)
 reduce_partials_kernel(const double* __restrict__ partial, int nsplit, int64_t stride, int64_t n,
-                       const double* __restrict__ addend, double* __restrict__ B, int* __restrict__ flag) {
+                       const double* __restrict__ addend, double* __restrict__ B, int* __restrict__ flag,
+                       SliceMap map) {
   __shared__ double sh[16][17];
   const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int64_t idx = (int64_t)blockIdx.x * 16 + e;
@@ -302,7 +328,7 @@ reduce_partials_kernel(const double* __restrict__ partial, int nsplit, int64_t s
 #pragma unroll
     for (int j = 0; j < 16; ++j) t += sh[j][e];
     if (addend != nullptr) t += addend[idx];
-    B[idx] = t;
+    B[slice_index(map, idx)] = t;
     if (!(fabs(t) <= 1.79769313486231570815e308)) atomicOr(flag, 1);
   }
 }
@@ -312,7 +338,8 @@ reduce_partials_kernel(const double* __restrict__ partial, int nsplit, int64_t s
 // so both give identical bits.
 __global__ void __launch_bounds__(256)
 reduce_partials_flat_kernel(const double* __restrict__ partial, int nsplit, int64_t stride, int64_t n,
-                            const double* __restrict__ addend, double* __restrict__ B, int* __restrict__ flag) {
+                            const double* __restrict__ addend, double* __restrict__ B, int* __restrict__ flag,
+                            SliceMap map) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n) return;
   double v[16];
@@ -322,7 +349,24 @@ reduce_partials_flat_kernel(const double* __restrict__ partial, int nsplit, int6
 #pragma unroll
   for (int sp = 0; sp < 16; ++sp) t += sp < nsplit ? v[sp] : 0.0;
   if (addend != nullptr) t += addend[idx];
-  B[idx] = t;
+  B[slice_index(map, idx)] = t;
+  if (!(fabs(t) <= 1.79769313486231570815e308)) atomicOr(flag, 1);
+}
+
+// The first `rows` rows of each of nf blocks of `rows_in` rows: out[f][r][d] = sum over the slabs of
+// partial[sp * stride + (f * rows_in + r) * D + d].  (The reference pre-pass of the single sweep needs the
+// projections on the first KR harmonics only; ascending slab order, as above.)
+__global__ void __launch_bounds__(256)
+reduce_rows_kernel(const double* __restrict__ partial, int nsplit, int64_t stride, int nf, int rows_in, int rows,
+                   int64_t D, double* __restrict__ out, int* __restrict__ flag) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t per = (int64_t)rows * D;
+  if (idx >= per * nf) return;
+  const int64_t f = idx / per, rem = idx - f * per;
+  const double* src = partial + f * rows_in * D + rem;
+  double t = 0.0;
+  for (int sp = 0; sp < nsplit; ++sp) t += src[(int64_t)sp * stride];
+  out[idx] = t;
   if (!(fabs(t) <= 1.79769313486231570815e308)) atomicOr(flag, 1);
 }
 

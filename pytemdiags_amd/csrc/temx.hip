@@ -101,6 +101,9 @@ struct temx_plan {
   // latitudes (Y0p itself stays the attribute), Ginv the inverse of the second Gram matrix Q^T Q (the identity up
   // to rounding), GinvA = T T^T the inverse of the Gram matrix of Y0 (attributes Y0inv / sanity numbers only).
   bool qbasis = false;
+  bool g_checker = false;      // the Gram matrix the plan was finalised with is a checkerboard (odd entries cleared)
+  bool ext_G = false;          // finalised with a Gram matrix from outside (ncol-sharded: the all-reduced one)
+  bool os_need_global = false; // single sweep: this rank's own subsample cannot be fitted, the job's matrices are awaited
   DevBuf T, Qp, GinvA, G2, xo, xc;
   int64_t cls_npad = 0;
   const double* yproj_ptr() const { return yblk_w.p ? yblk_w.d() : yblk.d(); }
@@ -131,13 +134,22 @@ struct temx_plan {
   // single-sweep form (kernels_op2.hpp, sweep_os_kernel): no class-sum stream; see build_os_tables / tem_run_os
   bool os_built = false, os_on = false;
   bool os_valid = false;               // Ax / rho / C4 are those of the latest single-sweep temx_tem_run (its v, omega serve the tracer)
-  DevBuf Axq, Ppq, rho_t;              // tracer in the single-sweep form
+  DevBuf Axq, rho_t;                   // tracer in the single-sweep form: [KX + 2 K][D] projections (+ [KR][D] pre-pass sums), references of (q, v, omega)
   int TBX = 0, KX = 0, KR = 0, NQ = 0;
   std::vector<double> h_xc, h_cnt;     // host copies of the class latitudes (cos colat) and member counts
   std::vector<int> h_crow;             // host copy of the row table
   std::vector<int> sgbatch0;           // subsample of class-groups (reference pre-pass): first batch of each (+ total)
   int64_t sgroups = 0, sbatches = 0;
-  DevBuf ycx, ycx_s, crow_s, rho, rho0, gaunt /* Yq[NQ][KX] */, wq2, Gx, Gsinv, Ax, Axs, Pp;
+  DevBuf ycx, ycx_s, crow_s, rho, rho0, gaunt /* Yq[NQ][KX] */, wq2, Gx, Gsinv, Ax /* [4 KX + 3 K][D]: projections of the fields, then of the products */, Axs /* [4][KR][D] */;
+  std::vector<double> h_Gx, h_Gs;      // this plan's rows: Y0^T Y0ext [K][KX] and the subsample's Gram matrix [KR][KR] (all-reduced when ncol-sharded)
+  int os_keep = 96;                    // class-groups of the reference subsample (TEMX_OPT_OS_SUBSAMPLE)
+  // what the tail of the pipeline (solve, contraction, scan, epilogue) currently describes: the snapshots
+  // [tt0, tt0 + tnt) of the run, tD = nlev * tnt columns.  The whole run unless a time-sliced tail ran last.
+  int64_t tD = 0, tnt = 0, tt0 = 0;
+  // path selection (temx_plan_configure; the TEMX_* environment variables override): -1 = automatic
+  int opt_form = -1, opt_os_map = -1, opt_op_map = -1, opt_tracer_one_pass = -1, opt_single_sweep_min_groups = -1;
+  bool os_tile = false, op_tile = false;   // effective lane map of the loads (fixed in temx_plan_set_tem)
+  bool no_qr = false;                      // TEMX_NO_QR (flag of temx_plan_create or environment)
   DevBuf side_crow[2][2], side_gfirst[2][2];   // [full table, subsample][north, south]: side_tables.hpp (sweep_os2_kernel)
   std::map<int, DevBuf> csplits_s;
   Split sp_os, sp_os_s;
@@ -394,18 +406,20 @@ static int launch_project(temx_plan* pl, const FieldPtrs<NF>& fp, int dtype, int
 
 // B[n] = (addend ? addend : 0) + sum over the nsplit slabs; slab sp starts at partial + sp * stride
 // (stride < 0: the slabs are dense, stride = n)
+// map: where entry idx of the sum goes (default: B[idx]; time slices for a reduce-scatter: kernels.hpp, SliceMap)
 static int launch_reduce(temx_plan* pl, const double* partial, int nsplit, int64_t n, double* B,
-                         hipStream_t st, int64_t stride = -1, const double* addend = nullptr) {
+                         hipStream_t st, int64_t stride = -1, const double* addend = nullptr,
+                         const SliceMap& map = SliceMap()) {
   if (stride < 0) stride = n;
   if (nsplit <= 16 && n >= 32768) {   // many entries, few slabs: one thread per entry (same bits)
     hipLaunchKernelGGL(reduce_partials_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial,
-                       nsplit, stride, n, addend, B, static_cast<int*>(pl->flag.p));
+                       nsplit, stride, n, addend, B, static_cast<int*>(pl->flag.p), map);
     HIPCHK(hipGetLastError());
     return TEMX_OK;
   }
   const int64_t blocks = (n + 15) / 16;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)blocks), dim3(256), 0, st, partial, nsplit, stride, n,
-                     addend, B, static_cast<int*>(pl->flag.p));
+                     addend, B, static_cast<int*>(pl->flag.p), map);
   HIPCHK(hipGetLastError());
   return TEMX_OK;
 }
@@ -891,10 +905,9 @@ static int launch_sweep_op_t(temx_plan* pl, const FieldPtrs<4>& fp, double* part
   constexpr int PDv = KIND == 1 ? (sizeof(T) == 4 ? 4 : 2) : (sizeof(T) == 4 ? TEMX_CLS_OP_PD_F32 : TEMX_CLS_OP_PD);
   // loads of 1 row x 64 columns (sweep_opr_kernel, kernels_op2.hpp) unless the last workgroup column would be
   // mostly padding (D = 72: 64 + 8) or TEMX_OP_MAP=tile asks for the tile form (A/B)
-  const char* em = getenv("TEMX_OP_MAP");
   const int64_t wcols = (pl->D + 63) / 64 * 64;
   // fp64 only: with fp32 inputs the tile form measured faster (ne240 x 128 x 1: 1.77 vs 2.08 ms, ne120 x 72 x 30: 7.2 vs 7.5)
-  const bool row_map = sizeof(T) == 8 && !(em && !strcmp(em, "tile")) && wcols * 100 <= pl->D * 115;
+  const bool row_map = sizeof(T) == 8 && !pl->op_tile && wcols * 100 <= pl->D * 115;
   constexpr int PDr = 2;
 #define TEMX_LSO(TBSv)                                                                                \
   do {                                                                                                \
@@ -1452,7 +1465,7 @@ static int build_os_tables(temx_plan* pl) {
       // subsample of class-groups for the reference fit: every S-th group, its batches copied
       // (about 100 class-groups = 400 latitudes for the 16 coefficients of a column; env TEMX_OS_SUBSAMPLE: groups kept)
       const char* ess = getenv("TEMX_OS_SUBSAMPLE");
-      const int64_t keep = ess ? std::max(16, atoi(ess)) : 96;
+      const int64_t keep = ess ? std::max(4, atoi(ess)) : pl->os_keep;
       const int64_t S = std::max<int64_t>(1, std::min<int64_t>(256, pl->cgroups / keep));
       std::vector<int> crow_s;
       std::vector<double> xc_s;
@@ -1505,11 +1518,21 @@ static int build_os_tables(temx_plan* pl) {
               for (int m = 0; m < KR; ++m) Gl[(size_t)l * KR + m] += (nN + (((l + m) & 1) ? -nS : nS)) * y[l] * y[m];
           }
         for (size_t i = 0; i < Gs.size(); ++i) Gs[i] = (double)Gl[i];
+        pl->h_Gs = Gs;
         std::vector<long double> Li;
         std::vector<double> Gi((size_t)KR * KR);
-        if (spd_factor(Gs.data(), KR, Li) != 0)
-          rc = fail(TEMX_ERANK, "the subsample of latitude classes does not determine a degree-%d reference", KR - 1);
-        else {
+        if (spd_factor(Gs.data(), KR, Li) != 0) {
+          // A rank of an ncol-sharded job owns a band of latitudes, which need not determine the fit on its own:
+          // the job's subsample is the union over the ranks, its Gram matrix comes through
+          // temx_plan_set_os_matrices (the sweeps refuse to run before that).
+          if (pl->ext_G) {
+            pl->os_need_global = true;
+            std::fill(Gi.begin(), Gi.end(), 0.0);
+            rc = upload(pl->Gsinv, Gi.data(), Gi.size() * 8);
+          } else {
+            rc = fail(TEMX_ERANK, "the subsample of latitude classes does not determine a degree-%d reference", KR - 1);
+          }
+        } else {
           inverse_from_factor(Li, KR, Gi.data());
           rc = upload(pl->Gsinv, Gi.data(), Gi.size() * 8);
         }
@@ -1540,8 +1563,7 @@ static int build_os_tables(temx_plan* pl) {
     const int nth = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     std::vector<std::vector<double>> part((size_t)nth, std::vector<double>((size_t)K * KX, 0.0));
     std::vector<std::thread> th;
-    for (int t = 0; t < nth; ++t)
-      th.emplace_back([&, t]() {
+    auto stripe = [&](int t) {
         std::vector<double> yy((size_t)KX);
         std::vector<long double> y((size_t)KX);
         std::vector<double>& Gp = part[(size_t)t];
@@ -1559,12 +1581,23 @@ static int build_os_tables(temx_plan* pl) {
             for (int k = 1 - (l & 1); k < KX; k += 2) row[k] += so * yl * yy[(size_t)k];    // l + k odd
           }
         }
-      });
+    };
+    // stripe t of the classes per thread; a thread that cannot be started (std::system_error under a process /
+    // thread limit -- this is an extern "C" call chain, nothing may propagate) leaves its stripe to the caller.
+    // The partial sums stay per stripe, so the result has the same bits however the stripes were run.
+    int started = 0;
+    try {
+      th.reserve((size_t)nth);
+      for (; started < nth - 1; ++started) th.emplace_back(stripe, started);
+    } catch (...) {
+    }
+    for (int t = started; t < nth; ++t) stripe(t);
     for (auto& x : th) x.join();
     std::vector<double> Gx((size_t)K * KX, 0.0);
     for (int t = 0; t < nth; ++t)          // fixed order: the same bits whatever the scheduling
       for (size_t i = 0; i < Gx.size(); ++i) Gx[i] += part[(size_t)t][i];
     if ((rc = upload(pl->Gx, Gx.data(), Gx.size() * 8))) return rc;
+    pl->h_Gx = std::move(Gx);
   }
   pl->os_built = true;
   return TEMX_OK;
@@ -1584,8 +1617,7 @@ static int launch_sweep_os_t(temx_plan* pl, const FieldPtrs<4>& fp, bool sub, co
   constexpr int PDv = sizeof(T) == 4 ? 4 : 2;       // (a 3-deep ring measured slower for the tracer kind: 8.7 vs 8.4 ms)
   constexpr int DF = TEMX_OS_DEFER;                 // projection of a finished class-group spread over the next 4 batches
   // loads of 1 row x 64 columns (sweep_osr_kernel, the default) or of 4 rows x 16 columns (TEMX_OS_MAP=tile, A/B)
-  const char* em = getenv("TEMX_OS_MAP");
-  const bool tile_map = em && !strcmp(em, "tile");
+  const bool tile_map = pl->os_tile;
   double* px = partial;
   double* pp = partial + (int64_t)sp.nsplit * KD::NFX * pl->KX * pl->D;
 #define TEMX_LOS(TBSv, TBXv)                                                                                        \
@@ -1650,27 +1682,79 @@ static bool os_active(const temx_plan* pl, int dtype) {
   return pl->os_on;
 }
 
-static int tem_run_os(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, double* results, double* zonal, void* stream) {
-  hipStream_t st = S_(stream);
+// The snapshots [t0, t0 + nts) the tail (solve, contraction, scan, epilogue) is about to describe.  Everything the
+// tail leaves in the plan (C4, zb, Ax, tz ...) then has nlev * nts columns.
+static void set_tail(temx_plan* pl, int64_t t0, int64_t nts) {
+  if (pl->tt0 != t0 || pl->tnt != nts) pl->c4_valid = pl->os_valid = pl->op_valid = pl->tq_valid = pl->xb_valid = false;
+  pl->tt0 = t0;
+  pl->tnt = nts;
+  pl->tD = (int64_t)pl->nlev * nts;
+}
+static inline bool tail_is_whole(const temx_plan* pl) { return pl->tt0 == 0 && pl->tnt == pl->nt; }
+
+static int tem_stage3_impl(temx_plan* pl, const double* B3, double* results, double* zonal, hipStream_t st);
+static int tracer_stage3_impl(temx_plan* pl, const double* Bq2, double* tres, double* tzon, hipStream_t st);
+
+// Time slices of a reduction (kernels.hpp, SliceMap): nsl slices, rows_total rows per slice
+static SliceMap slice_map(const temx_plan* pl, int nsl, int64_t rows_total, int64_t row0) {
+  SliceMap m;
+  if (nsl <= 1) return m;
+  m.D = pl->D;
+  m.nt = (int)pl->nt;
+  m.W = nsl;
+  m.chunk = rows_total * pl->nlev * ((pl->nt + nsl - 1) / nsl);
+  m.row0 = row0;
+  return m;
+}
+
+// ---- the single sweep in three steps.  A single process runs them back to back (tem_run_os); an ncol-sharded job
+// exchanges between them: (1) -> all-reduce of As (4 x KR x D doubles) -> (2) -> reduce-scatter of proj over time
+// -> (3) on the snapshots the rank received.
+// 1. reference pre-pass: the same sweep over the subsample of class-groups with a zero reference; As[4][KR][D] =
+//    raw sums of the four fields on the first KR harmonics (this rank's rows)
+static int os_prepass(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, double* As, hipStream_t st) {
+  int rc;
+  const int64_t D = pl->D, KD4 = (int64_t)4 * pl->KX * D;
+  pl->op_valid = pl->c4_valid = pl->tq_valid = pl->os_valid = false;       // no class sums on this path
+  if ((rc = launch_sweep_os<0>(pl, fp, dtype, true, pl->rho0.d(), pl->partial.d(), pl->sp_os_s, st))) return rc;
+  const int64_t n = (int64_t)4 * pl->KR * D;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pl->partial.d(), pl->sp_os_s.nsplit,
+                     KD4, 4, pl->KX, pl->KR, D, As, static_cast<int*>(pl->flag.p));
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+// 2. reference coefficients from the (global) subsample sums, the sweep, and its reduction: proj = [4 KX + 3 K] rows
+//    (projections of the shifted fields to degree 2L, of their products to degree L), whole ([rows][D]) or cut into
+//    nsl time slices ([nsl][rows][nlev][ceil(nt / nsl)], the input of a reduce-scatter)
+static int os_sweep(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, const double* As, int nsl, double* proj, hipStream_t st) {
   int rc;
   const int64_t D = pl->D;
   const int64_t KD4 = (int64_t)4 * pl->KX * D, KD3 = (int64_t)3 * pl->K * D;
-  pl->op_valid = pl->c4_valid = pl->tq_valid = pl->os_valid = false;       // no class sums on this path
-  // 1. reference: the same sweep over the subsample with a zero reference, degree < KR fit
-  if ((rc = launch_sweep_os<0>(pl, fp, dtype, true, pl->rho0.d(), pl->partial.d(), pl->sp_os_s, st))) return rc;
-  if ((rc = launch_reduce(pl, pl->partial.d(), pl->sp_os_s.nsplit, KD4, pl->Axs.d(), st))) return rc;
-  hipLaunchKernelGGL(os_ref_solve_kernel, dim3((unsigned)((D + 255) / 256), 4), dim3(256), 0, st, pl->Axs.d(), pl->KX, pl->KR, D,
+  pl->op_valid = pl->c4_valid = pl->tq_valid = pl->os_valid = false;
+  hipLaunchKernelGGL(os_ref_solve_kernel, dim3((unsigned)((D + 255) / 256), 4), dim3(256), 0, st, As, pl->KR, pl->KR, D,
                      pl->Gsinv.d(), pl->rho.d());
   HIPCHK(hipGetLastError());
-  // 2. the sweep
   TimedLaunch tl{};
   time_begin(pl, 0, st, tl);
   rc = launch_sweep_os<0>(pl, fp, dtype, false, pl->rho.d(), pl->partial.d(), pl->sp_os, st);
   time_end(pl, 0, st, tl);
   if (rc) return rc;
-  if ((rc = launch_reduce(pl, pl->partial.d(), pl->sp_os.nsplit, KD4, pl->Ax.d(), st))) return rc;
-  if ((rc = launch_reduce(pl, pl->partial.d() + (int64_t)pl->sp_os.nsplit * KD4, pl->sp_os.nsplit, KD3, pl->Pp.d(), st))) return rc;
-  // 3. linearisation: raw sums of the fields and of the eddy products in the plan's basis
+  const int64_t rows = (int64_t)4 * pl->KX + 3 * pl->K;
+  if ((rc = launch_reduce(pl, pl->partial.d(), pl->sp_os.nsplit, KD4, proj, st, -1, nullptr, slice_map(pl, nsl, rows, 0)))) return rc;
+  return launch_reduce(pl, pl->partial.d() + (int64_t)pl->sp_os.nsplit * KD4, pl->sp_os.nsplit, KD3, nsl > 1 ? proj : proj + KD4, st, -1,
+                       nullptr, slice_map(pl, nsl, rows, (int64_t)4 * pl->KX));
+}
+
+// 3. the tail for the snapshots [t0, t0 + nts): linearisation (raw sums of the fields and of the eddy products in the
+//    plan's basis), coefficients and zonal means, epilogue.  proj_s: [4 KX + 3 K][nlev][nts], summed over the ranks.
+static int os_tail(temx_plan* pl, const double* proj_s, int64_t t0, int64_t nts, double* results, double* zonal, hipStream_t st) {
+  int rc;
+  set_tail(pl, t0, nts);
+  const int64_t Dt = pl->tD;
+  const int64_t rows = (int64_t)4 * pl->KX + 3 * pl->K;
+  if (proj_s != pl->Ax.d())       // the plan keeps the slice: the tracer's single sweep reuses the projections of v and omega
+    HIPCHK(hipMemcpyAsync(pl->Ax.p, proj_s, (size_t)rows * Dt * 8, hipMemcpyDeviceToDevice, st));
   {
     TimedLaunch t2{};
     time_begin(pl, 1, st, t2);
@@ -1679,21 +1763,29 @@ static int tem_run_os(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, double* 
     if ((rc = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(os_contract_kernel<0>), 160 * 1024))) return rc;
     OsFields in;
     for (int f = 0; f < 4; ++f) {
-      in.A[f] = pl->Ax.d() + (int64_t)f * pl->KX * D;
-      in.rho[f] = pl->rho.d() + (int64_t)f * pl->KR * D;
+      in.A[f] = pl->Ax.d() + (int64_t)f * pl->KX * Dt;
+      in.rho[f] = pl->rho.d() + (int64_t)f * pl->KR * pl->D;
     }
-    hipLaunchKernelGGL(os_contract_kernel<0>, dim3((unsigned)((D + OSC - 1) / OSC)), dim3(256), lds, st, in, pl->Pp.d(),
-                       pl->K, pl->KX, pl->KR, pl->NQ, D, pl->T.d(), pl->Ginv.d(), pl->G.d(), pl->Gx.d(),
-                       pl->gaunt.d(), pl->wq2.d(), pl->B4.d(), pl->B3.d());
+    hipLaunchKernelGGL(os_contract_kernel<0>, dim3((unsigned)((Dt + OSC - 1) / OSC)), dim3(256), lds, st, in,
+                       pl->Ax.d() + (int64_t)4 * pl->KX * Dt, pl->K, pl->KX, pl->KR, pl->NQ, Dt, pl->T.d(), pl->Ginv.d(), pl->G.d(),
+                       pl->Gx.d(), pl->gaunt.d(), pl->wq2.d(), pl->B4.d(), pl->B3.d(), pl->D, (int)nts, (int)pl->nt, (int)t0);
     HIPCHK(hipGetLastError());
     time_end(pl, 1, st, t2);
   }
-  // 4. as after stage 2: coefficients and zonal means of the four fields, then the epilogue
-  if ((rc = launch_solve(pl, pl->B4.d(), 4, D, pl->C4.d(), pl->zb.d(), st))) return rc;
+  // as after stage 2: coefficients and zonal means of the four fields, then the epilogue
+  if ((rc = launch_solve(pl, pl->B4.d(), 4, Dt, pl->C4.d(), pl->zb.d(), st))) return rc;
+  if ((rc = tem_stage3_impl(pl, pl->B3.d(), results, zonal, st))) return rc;
   pl->c4_valid = true;
-  if ((rc = temx_tem_stage3(pl, pl->B3.d(), results, zonal, stream))) return rc;
-  pl->os_valid = true;            // Ax, rho describe these fields: the tracer's single sweep may follow
+  pl->os_valid = true;            // Ax, rho describe these fields (and these snapshots): the tracer's single sweep may follow
   return TEMX_OK;
+}
+
+static int tem_run_os(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, double* results, double* zonal, void* stream) {
+  hipStream_t st = S_(stream);
+  int rc;
+  if ((rc = os_prepass(pl, fp, dtype, pl->Axs.d(), st))) return rc;
+  if ((rc = os_sweep(pl, fp, dtype, pl->Axs.d(), 1, pl->Ax.d(), st))) return rc;
+  return os_tail(pl, pl->Ax.d(), 0, pl->nt, results, zonal, st);
 }
 
 static int tracer_ws(temx_plan* pl);
@@ -1701,50 +1793,84 @@ static int tracer_ws(temx_plan* pl);
 // Tracer in the single-sweep form: (q, v, omega) read once, no class sums.  The degree-2L projections and the
 // references of v and omega are those the TEM run left in the plan (os_valid): the same v and omega must be
 // handed over.  q gets its own reference from a pre-pass, is projected to degree 2L, q v and q omega to degree L.
-static int tracer_run_os(temx_plan* pl, const void* q, const void* va, const void* wap, int dtype, double* tres,
-                         double* tzon, void* stream) {
-  hipStream_t st = S_(stream);
+// The same three steps as the TEM run; Asq[KR][D], projq = [KX + 2 K] rows.
+static int tracer_os_ws(temx_plan* pl) {
+  const int64_t D = pl->D;
+  int rc;
+  if ((rc = tracer_ws(pl))) return rc;
+  if ((rc = pl->Axq.ensure((size_t)(pl->KX + 2 * pl->K + pl->KR) * D * 8))) return rc;   // projections, then the pre-pass sums
+  return pl->rho_t.ensure((size_t)3 * pl->KR * D * 8);
+}
+
+static int tracer_os_prepass(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, double* Asq, hipStream_t st) {
+  int rc;
+  const int64_t D = pl->D;
+  if ((rc = tracer_os_ws(pl))) return rc;
+  pl->tq_valid = false;
+  // (the references of v, omega do not matter here: only q's projection is used)
+  if ((rc = launch_sweep_os<1>(pl, fp, dtype, true, pl->rho0.d(), pl->partial.d(), pl->sp_os_s, st))) return rc;
+  const int64_t n = (int64_t)pl->KR * D;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pl->partial.d(), pl->sp_os_s.nsplit,
+                     (int64_t)pl->KX * D, 1, pl->KX, pl->KR, D, Asq, static_cast<int*>(pl->flag.p));
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
+static int tracer_os_sweep(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, const double* Asq, int nsl, double* projq, hipStream_t st) {
   int rc;
   const int64_t D = pl->D, KXD = (int64_t)pl->KX * D, KD = (int64_t)pl->K * D, KRD = (int64_t)pl->KR * D;
-  if ((rc = tracer_ws(pl))) return rc;
-  if ((rc = pl->Axq.ensure((size_t)2 * KXD * 8))) return rc;          // [0]: main run, [1]: pre-pass
-  if ((rc = pl->Ppq.ensure((size_t)2 * KD * 8))) return rc;
-  if ((rc = pl->rho_t.ensure((size_t)3 * KRD * 8))) return rc;
-  const FieldPtrs<4> fp = four(q, va, wap, nullptr);
+  if ((rc = tracer_os_ws(pl))) return rc;
   pl->tq_valid = false;
-  // reference of q from the subsample (the references of v, omega do not matter there: only q's projection is used)
-  if ((rc = launch_sweep_os<1>(pl, fp, dtype, true, pl->rho0.d(), pl->partial.d(), pl->sp_os_s, st))) return rc;
-  if ((rc = launch_reduce(pl, pl->partial.d(), pl->sp_os_s.nsplit, KXD, pl->Axq.d() + KXD, st))) return rc;
-  hipLaunchKernelGGL(os_ref_solve_kernel, dim3((unsigned)((D + 255) / 256), 1), dim3(256), 0, st, pl->Axq.d() + KXD, pl->KX,
-                     pl->KR, D, pl->Gsinv.d(), pl->rho_t.d());
+  hipLaunchKernelGGL(os_ref_solve_kernel, dim3((unsigned)((D + 255) / 256), 1), dim3(256), 0, st, Asq, pl->KR, pl->KR, D,
+                     pl->Gsinv.d(), pl->rho_t.d());
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(pl->rho_t.d() + KRD, pl->rho.d() + 1 * KRD, (size_t)KRD * 8, hipMemcpyDeviceToDevice, st));   // v
   HIPCHK(hipMemcpyAsync(pl->rho_t.d() + 2 * KRD, pl->rho.d() + 3 * KRD, (size_t)KRD * 8, hipMemcpyDeviceToDevice, st));   // omega
   if ((rc = launch_sweep_os<1>(pl, fp, dtype, false, pl->rho_t.d(), pl->partial.d(), pl->sp_os, st))) return rc;
-  if ((rc = launch_reduce(pl, pl->partial.d(), pl->sp_os.nsplit, KXD, pl->Axq.d(), st))) return rc;
-  if ((rc = launch_reduce(pl, pl->partial.d() + (int64_t)pl->sp_os.nsplit * KXD, pl->sp_os.nsplit, 2 * KD, pl->Ppq.d(), st))) return rc;
+  const int64_t rows = (int64_t)pl->KX + 2 * pl->K;
+  if ((rc = launch_reduce(pl, pl->partial.d(), pl->sp_os.nsplit, KXD, projq, st, -1, nullptr, slice_map(pl, nsl, rows, 0)))) return rc;
+  return launch_reduce(pl, pl->partial.d() + (int64_t)pl->sp_os.nsplit * KXD, pl->sp_os.nsplit, 2 * KD, nsl > 1 ? projq : projq + KXD, st,
+                       -1, nullptr, slice_map(pl, nsl, rows, pl->KX));
+}
+
+// the tracer's tail for the snapshots the TEM tail worked on (set_tail): projq_s [KX + 2 K][nlev][tnt]
+static int tracer_os_tail(temx_plan* pl, const double* projq_s, double* tres, double* tzon, hipStream_t st) {
+  int rc;
+  const int64_t Dt = pl->tD, KXD = (int64_t)pl->KX * Dt, KRD = (int64_t)pl->KR * pl->D;
   {
     const size_t lds = os_contract_lds(pl->K, pl->KX, pl->NQ) * 8;
     static std::atomic<uint64_t> attr_set{0};
     if ((rc = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(os_contract_kernel<1>), 160 * 1024))) return rc;
     OsFields in{};
-    in.A[0] = pl->Axq.d();
+    in.A[0] = projq_s;
     in.A[1] = pl->Ax.d() + 1 * KXD;
     in.A[2] = pl->Ax.d() + 3 * KXD;
     in.rho[0] = pl->rho_t.d();
     in.rho[1] = pl->rho.d() + 1 * KRD;
     in.rho[2] = pl->rho.d() + 3 * KRD;
-    hipLaunchKernelGGL(os_contract_kernel<1>, dim3((unsigned)((D + OSC - 1) / OSC)), dim3(256), lds, st, in, pl->Ppq.d(),
-                       pl->K, pl->KX, pl->KR, pl->NQ, D, pl->T.d(), pl->Ginv.d(), pl->G.d(), pl->Gx.d(), pl->gaunt.d(),
-                       pl->wq2.d(), pl->Bq.d(), pl->Bq2.d());
+    hipLaunchKernelGGL(os_contract_kernel<1>, dim3((unsigned)((Dt + OSC - 1) / OSC)), dim3(256), lds, st, in, projq_s + KXD,
+                       pl->K, pl->KX, pl->KR, pl->NQ, Dt, pl->T.d(), pl->Ginv.d(), pl->G.d(), pl->Gx.d(), pl->gaunt.d(),
+                       pl->wq2.d(), pl->Bq.d(), pl->Bq2.d(), pl->D, (int)pl->tnt, (int)pl->nt, (int)pl->tt0);
     HIPCHK(hipGetLastError());
   }
   // coefficients Ct = (C_q, C_v, C_w) and qb -> tz[0], as the other tracer stage 2 forms leave them
-  const size_t slab = (size_t)pl->K4 * D * 8;
-  if ((rc = launch_solve(pl, pl->Bq.d(), 1, D, pl->Ct.d(), pl->tz.d(), st))) return rc;
+  const size_t slab = (size_t)pl->K4 * Dt * 8;
+  if ((rc = launch_solve(pl, pl->Bq.d(), 1, Dt, pl->Ct.d(), pl->tz.d(), st))) return rc;
   HIPCHK(hipMemcpyAsync((char*)pl->Ct.p + slab, (char*)pl->C4.p + slab, slab, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpyAsync((char*)pl->Ct.p + 2 * slab, (char*)pl->C4.p + 3 * slab, slab, hipMemcpyDeviceToDevice, st));
-  return temx_tracer_stage3(pl, pl->Bq2.d(), tres, tzon, stream);
+  return tracer_stage3_impl(pl, pl->Bq2.d(), tres, tzon, st);
+}
+
+static int tracer_run_os(temx_plan* pl, const void* q, const void* va, const void* wap, int dtype, double* tres,
+                         double* tzon, void* stream) {
+  hipStream_t st = S_(stream);
+  int rc;
+  if ((rc = tracer_os_ws(pl))) return rc;
+  const FieldPtrs<4> fp = four(q, va, wap, nullptr);
+  double* Asq = pl->Axq.d() + (int64_t)(pl->KX + 2 * pl->K) * pl->D;
+  if ((rc = tracer_os_prepass(pl, fp, dtype, Asq, st))) return rc;
+  if ((rc = tracer_os_sweep(pl, fp, dtype, Asq, 1, pl->Axq.d(), st))) return rc;
+  return tracer_os_tail(pl, pl->Axq.d(), tres, tzon, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1752,7 +1878,7 @@ static int tracer_run_os(temx_plan* pl, const void* q, const void* va, const voi
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int temx_version(void) { return 300; }
+int temx_version(void) { return 400; }
 
 const char* temx_last_error(void) { return g_err.c_str(); }
 
@@ -1783,7 +1909,7 @@ void temx_plan_destroy(temx_plan* pl) {
   pl->ypblk.release();
   for (DevBuf* b : {&pl->T, &pl->Qp, &pl->GinvA, &pl->G2, &pl->xo, &pl->xc, &pl->ycx, &pl->ycx_s, &pl->crow_s, &pl->side_crow[0][0], &pl->side_crow[0][1], &pl->side_crow[1][0], &pl->side_crow[1][1],
                     &pl->side_gfirst[0][0], &pl->side_gfirst[0][1], &pl->side_gfirst[1][0], &pl->side_gfirst[1][1], &pl->rho,
-                    &pl->rho0, &pl->gaunt, &pl->wq2, &pl->Axq, &pl->Ppq, &pl->rho_t, &pl->Gx, &pl->Gsinv, &pl->Ax, &pl->Axs, &pl->Pp})
+                    &pl->rho0, &pl->gaunt, &pl->wq2, &pl->Axq, &pl->rho_t, &pl->Gx, &pl->Gsinv, &pl->Ax, &pl->Axs})
     b->release();
   for (auto& kv : pl->csplits_s) kv.second.release();
   for (auto& kv : pl->csplits) kv.second.release();
@@ -1881,6 +2007,7 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
 
   temx_plan* pl = new temx_plan();
   pl->device = device;
+  pl->no_qr = (flags & TEMX_NO_QR) != 0;
   pl->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   pl->N = ncol;
   pl->nchunk = (ncol + 15) / 16;
@@ -2088,7 +2215,9 @@ int temx_plan_finalize(temx_plan* pl, const double* G_host) {
       if ((i + j) & 1) odd_max = std::max(odd_max, std::fabs(G[(size_t)i * K + j]));
   }
   const bool checker = odd_max <= 1e-10 * diag_max;
-  if (parity_paths && checker)
+  pl->ext_G = G_host != nullptr;
+  pl->g_checker = checker && (G_host != nullptr || parity_paths);
+  if (pl->g_checker)
     for (int i = 0; i < K; ++i)
       for (int j = 0; j < K; ++j)
         if ((i + j) & 1) G[(size_t)i * K + j] = 0.0;
@@ -2105,8 +2234,12 @@ int temx_plan_finalize(temx_plan* pl, const double* G_host) {
     pl->rank = K;
   }
   if (int rca = upload(pl->GinvA, Gi.data(), Gi.size() * 8)) return rca;
-  static const bool no_qr = [] { const char* e = getenv("TEMX_NO_QR"); return e && e[0] == '1'; }();
-  const bool want_q = spd && !no_qr && (!parity_paths || checker);
+  const char* eq = getenv("TEMX_NO_QR");
+  const bool no_qr = eq ? eq[0] == '1' : pl->no_qr;
+  // Q = Y0 R^-1 keeps the parity of the harmonics only when G is a checkerboard (an equatorially symmetric grid);
+  // the class / paired sweeps need that.  With an external G (ncol-sharded: the all-reduced one) every rank must
+  // make the SAME choice whatever sweeps its own block of columns runs, so the choice depends on G alone there.
+  const bool want_q = spd && !no_qr && (G_host ? checker : (!parity_paths || checker));
   if (want_q) {
     std::vector<double> T((size_t)K * K, 0.0), I((size_t)K * K, 0.0);
     for (int l = 0; l < K; ++l) {
@@ -2144,7 +2277,7 @@ int temx_plan_refine(temx_plan* pl, const double* G2_host) {
   }
   for (double v : G2)
     if (!std::isfinite(v)) return fail(TEMX_EINVAL, "second Gram matrix is not finite");
-  if (pl->sym || pl->cls || pl->lcls)              // same parity argument as in temx_plan_finalize
+  if (pl->g_checker)                               // same parity argument as in temx_plan_finalize
     for (int i = 0; i < K; ++i)
       for (int j = 0; j < K; ++j)
         if ((i + j) & 1) G2[(size_t)i * K + j] = 0.0;
@@ -2233,9 +2366,38 @@ int temx_get_matrix(temx_plan* pl, int which, double* dst, void* stream) {
       HIPCHK(hipMemcpyAsync(dst, pl->G2.p, KK, hipMemcpyDeviceToDevice, st));
       return TEMX_OK;
     }
+    case TEMX_MAT_GX:
+    case TEMX_MAT_GSUB: {
+      if (!pl->os_built) return fail(TEMX_ESTATE, "the single-sweep tables are not built (temx_plan_set_tem on a plan that takes that form)");
+      const std::vector<double>& h = which == TEMX_MAT_GX ? pl->h_Gx : pl->h_Gs;
+      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(hipMemcpy(dst, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+      return TEMX_OK;
+    }
     default:
       return fail(TEMX_EINVAL, "unknown matrix id %d", which);
   }
+}
+
+// ncol-sharded single sweep: the two matrices of build_os_tables that sum over the rows -- Gx = Y0^T Y0ext [K][2L+1]
+// and the Gram matrix of the reference subsample [KR][KR] -- summed over the ranks (all-reduce of
+// temx_get_matrix(TEMX_MAT_GX / TEMX_MAT_GSUB)), handed back.
+int temx_plan_set_os_matrices(temx_plan* pl, const double* Gx_host, const double* Gs_host) {
+  if (!pl || !Gx_host || !Gs_host) return fail(TEMX_EINVAL, "null argument");
+  if (!pl->os_built) return fail(TEMX_ESTATE, "the single-sweep tables are not built");
+  HIPCHK(hipSetDevice(pl->device));
+  const int KR = pl->KR;
+  std::vector<long double> Li;
+  std::vector<double> Gi((size_t)KR * KR);
+  if (spd_factor(Gs_host, KR, Li) != 0)
+    return fail(TEMX_ERANK, "the subsample of latitude classes does not determine a degree-%d reference", KR - 1);
+  inverse_from_factor(Li, KR, Gi.data());
+  HIPCHK(hipDeviceSynchronize());
+  if (int rc = upload(pl->Gsinv, Gi.data(), Gi.size() * 8)) return rc;
+  if (int rc = upload(pl->Gx, Gx_host, (size_t)pl->K * pl->KX * 8)) return rc;
+  pl->os_need_global = false;
+  pl->os_valid = false;
+  return TEMX_OK;
 }
 
 // ---- operator API --------------------------------------------------------------------------------
@@ -2280,6 +2442,71 @@ int temx_zonal_mean(temx_plan* pl, const void* A, int dtype, int64_t D, double* 
   return temx_zonal_mean_from_sums(pl, pl->opB.d(), D, out, native, stream);
 }
 
+// ---- path selection: temx_plan_configure sets the options, the TEMX_* environment variables override them ------
+struct FormChoice {
+  bool two_pass;      // the class path in its two-pass form
+  bool force_op;      // the one-pass form wherever it is possible (lifts the size threshold)
+  int os;             // single sweep: 0 never, 1 wherever the instantiations exist, -1 automatic
+};
+static FormChoice form_choice(const temx_plan* pl) {
+  FormChoice c{false, false, -1};
+  switch (pl->opt_form) {
+    case TEMX_FORM_TWO_PASS: c.two_pass = true; c.os = 0; break;
+    case TEMX_FORM_CLASS_SUMS: c.force_op = true; c.os = 0; break;
+    case TEMX_FORM_SINGLE_SWEEP: c.force_op = true; c.os = 1; break;
+    case TEMX_FORM_NO_SINGLE_SWEEP: c.os = 0; break;
+    default: break;
+  }
+  if (const char* e = getenv("TEMX_TWO_PASS")) c.two_pass = e[0] == '1';
+  if (const char* e = getenv("TEMX_ONE_PASS")) c.force_op = c.force_op || e[0] == '1';
+  if (const char* e = getenv("TEMX_SINGLE_SWEEP")) c.os = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : c.os);
+  return c;
+}
+// 1: loads of 4 rows x 16 columns (the MFMA tile), 0: loads of 1 row x 64 columns
+static bool tile_map(int opt, const char* env) {
+  if (const char* e = getenv(env)) return !strcmp(e, "tile");
+  return opt == 1;
+}
+static bool tracer_one_pass_wanted(const temx_plan* pl) {
+  if (const char* e = getenv("TEMX_TRACER_ONE_PASS")) return e[0] == '1';
+  return pl->opt_tracer_one_pass == 1;
+}
+
+int temx_plan_configure(temx_plan* pl, int option, int value) {
+  if (!pl) return fail(TEMX_EINVAL, "null plan");
+  switch (option) {
+    case TEMX_OPT_FORM:
+      if (value < -1 || value > TEMX_FORM_NO_SINGLE_SWEEP) return fail(TEMX_EINVAL, "TEMX_OPT_FORM: unknown form %d", value);
+      pl->opt_form = value;
+      break;
+    case TEMX_OPT_OS_MAP: pl->opt_os_map = value; break;
+    case TEMX_OPT_OP_MAP: pl->opt_op_map = value; break;
+    case TEMX_OPT_TRACER_ONE_PASS: pl->opt_tracer_one_pass = value; break;
+    case TEMX_OPT_OS_SUBSAMPLE:
+      if (value < 4) return fail(TEMX_EINVAL, "TEMX_OPT_OS_SUBSAMPLE: at least 4 class-groups");
+      if (pl->os_built && value != pl->os_keep) return fail(TEMX_ESTATE, "the single-sweep tables of this plan are built: set the subsample before temx_plan_set_tem");
+      pl->os_keep = value;
+      break;
+    case TEMX_OPT_SINGLE_SWEEP_MIN_GROUPS: pl->opt_single_sweep_min_groups = value; break;
+    default: return fail(TEMX_EINVAL, "unknown option %d", option);
+  }
+  pl->tem = false;                // the choice is made in temx_plan_set_tem: call it (again)
+  return TEMX_OK;
+}
+
+int temx_plan_option(const temx_plan* pl, int option) {
+  if (!pl) return -1;
+  switch (option) {
+    case TEMX_OPT_FORM: return pl->os_on ? TEMX_FORM_SINGLE_SWEEP : ((pl->cls && pl->onepass) || (pl->lcls && pl->lone) ? TEMX_FORM_CLASS_SUMS : TEMX_FORM_TWO_PASS);
+    case TEMX_OPT_OS_MAP: return tile_map(pl->opt_os_map, "TEMX_OS_MAP") ? 1 : 0;
+    case TEMX_OPT_OP_MAP: return tile_map(pl->opt_op_map, "TEMX_OP_MAP") ? 1 : 0;
+    case TEMX_OPT_TRACER_ONE_PASS: return tracer_one_pass_wanted(pl) ? 1 : 0;
+    case TEMX_OPT_OS_SUBSAMPLE: return pl->os_keep;
+    case TEMX_OPT_SINGLE_SWEEP_MIN_GROUPS: return pl->opt_single_sweep_min_groups;
+    default: return -1;
+  }
+}
+
 // ---- TEM pipeline --------------------------------------------------------------------------------
 int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_host, double p0) {
   if (!pl || !p_pa_host) return fail(TEMX_EINVAL, "null argument");
@@ -2295,9 +2522,14 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
   pl->tem = false;
   pl->onepass = pl->lone = pl->op_valid = pl->xb_valid = pl->tq_valid = false;
   pl->os_on = pl->os_valid = false;
+  pl->os_tile = tile_map(pl->opt_os_map, "TEMX_OS_MAP");
+  pl->op_tile = tile_map(pl->opt_op_map, "TEMX_OP_MAP");
   pl->nlev = nlev;
   pl->nt = nt;
   pl->D = (int64_t)nlev * nt;
+  pl->tD = pl->D;
+  pl->tnt = nt;
+  pl->tt0 = 0;
   pl->p0 = p0;
   const int M = pl->M;
   const int64_t D = pl->D;
@@ -2350,10 +2582,9 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
   pl->xb_valid = false;
   pl->op_valid = false;      // class sums of an earlier configuration are void
   if (pl->lcls) {    // large-L class path: class sums first (kernels_cls.hpp), if they fit
-    const char* e2 = getenv("TEMX_TWO_PASS");
     const size_t need_cs = (size_t)pl->cgroups * ndt_ * 14 * 64 * 8, need_pb = (size_t)pl->cgroups * ndt_ * 3 * 128 * 8;
     size_t fr = 0, tot = 0;
-    if (ndt_ >= 4 && !(e2 && e2[0] == '1') && hipMemGetInfo(&fr, &tot) == hipSuccess &&
+    if (ndt_ >= 4 && !form_choice(pl).two_pass && hipMemGetInfo(&fr, &tot) == hipSuccess &&
         (pl->csum.bytes >= need_cs || need_cs + need_pb < fr / 2) && alloc_write_stream(pl->csum, need_cs) == TEMX_OK &&
         pl->pbuf.ensure(need_pb) == TEMX_OK) {
       HIPCHK(hipMemset(pl->csum.p, 0, pl->csum.bytes));
@@ -2386,15 +2617,14 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
     pl->onepass = false;
     pl->op_valid = false;
     {
-      const char* e2 = getenv("TEMX_TWO_PASS");
-      const char* e3 = getenv("TEMX_ONE_PASS");   // =1: whenever possible (tests)
-      const bool force = e3 && e3[0] == '1';
+      const FormChoice fc = form_choice(pl);
+      const bool force = fc.force_op;             // whenever possible (tests)
       // a ragged last quad only idles a few waves.  The one-pass sweep runs one wave per SIMD, which
       // pays once there is enough work: measured break-even near 1.2e7 elements per field
       // (ne30x72x2, 7e6: 0.137 ms two-pass vs 0.156; ne30x72x4, 1.4e7: 0.223 vs 0.203;
       // ne120x72x2, 1.1e8: 1.44 vs 1.18)
       const bool quad_op = ndt_ >= 4 && (force || (double)pl->N * (double)D >= 1.2e7);
-      if (quad_op && !(e2 && e2[0] == '1')) {
+      if (quad_op && !fc.two_pass) {
         const size_t need_cs = (size_t)pl->cgroups * ndt_ * 8 * 64 * 8;   // 4 {north, south} pairs per lane
         size_t fr = 0, tot = 0;
         bool have = pl->csum.bytes >= need_cs;
@@ -2416,9 +2646,9 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
           // and the grid has enough latitude classes for the reference fit; TEMX_SINGLE_SWEEP=0 keeps the
           // class-sum form, =1 also takes it on small grids
           {
-            const char* es = getenv("TEMX_SINGLE_SWEEP");
-            const bool off = es && es[0] == '0', forced = es && es[0] == '1';
-            bool want = !off && os_supported(pl) && (forced || pl->cgroups >= 2048);
+            const bool off = fc.os == 0, forced = fc.os == 1;
+            const int64_t min_groups = pl->opt_single_sweep_min_groups >= 0 ? pl->opt_single_sweep_min_groups : 2048;
+            bool want = !off && os_supported(pl) && (forced || pl->cgroups >= min_groups);
             if (want) {
               rc = build_os_tables(pl);
               if (rc == TEMX_ERANK) want = false;          // too few distinct latitudes in the subsample: class-sum form
@@ -2430,9 +2660,8 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
               pl->sp_os_s = choose_split(D, std::max<int64_t>(1, pl->sbatches / 4), std::max(1, pl->num_cu / 2), 4, 2);
               const size_t per = ((size_t)4 * pl->KX + 3 * pl->K) * D * 8;
               if ((rc = pl->partial.ensure(std::max((size_t)std::max(pl->sp_os.nsplit, pl->sp_os_s.nsplit) * per, pl->partial.bytes)))) return rc;
-              if ((rc = pl->Ax.ensure((size_t)4 * pl->KX * D * 8))) return rc;
-              if ((rc = pl->Axs.ensure((size_t)4 * pl->KX * D * 8))) return rc;
-              if ((rc = pl->Pp.ensure((size_t)3 * pl->K * D * 8))) return rc;
+              if ((rc = pl->Ax.ensure(((size_t)4 * pl->KX + 3 * pl->K) * D * 8))) return rc;
+              if ((rc = pl->Axs.ensure((size_t)4 * pl->KR * D * 8))) return rc;
               if ((rc = pl->rho.ensure((size_t)4 * pl->KR * D * 8))) return rc;
               if ((rc = pl->rho0.ensure((size_t)4 * pl->KR * D * 8))) return rc;
               HIPCHK(hipMemset(pl->rho0.p, 0, pl->rho0.bytes));
@@ -2487,6 +2716,7 @@ int temx_tem_stage1(temx_plan* pl, const void* ua, const void* va, const void* t
   hipStream_t st = S_(stream);
   FieldPtrs<4> fp;
   fp.p[0] = ua; fp.p[1] = va; fp.p[2] = ta; fp.p[3] = wap;
+  if (pl->large) set_tail(pl, 0, pl->nt);
   if (pl->large && pl->lone) {   // class sums first, then their projection slice by slice
     pl->op_valid = false;
     if ((rc = launch_class_sums(pl, fp, dtype, st))) return rc;
@@ -2500,6 +2730,7 @@ int temx_tem_stage1(temx_plan* pl, const void* ua, const void* va, const void* t
   const bool sp4 = sym_project(pl, 4);
   const Split& sp = pl->cls ? pl->sp_cproj4 : (sp4 ? pl->sp_sproj4 : pl->sp_proj4);
   const bool op = pl->cls && pl->onepass;
+  set_tail(pl, 0, pl->nt);
   pl->op_valid = false;
   pl->os_valid = false;
   pl->c4_valid = false;          // C4 still describes the previous fields until a stage-2 solve has run
@@ -2599,6 +2830,7 @@ int temx_tem_stage2(temx_plan* pl, const void* ua, const void* va, const void* t
   if (!ua || !va || !ta || !wap || !B4 || !B3) return fail(TEMX_EINVAL, "null argument");
   HIPCHK(hipSetDevice(pl->device));
   hipStream_t st = S_(stream);
+  set_tail(pl, 0, pl->nt);
   if (unfused_stage2(pl)) return tem_stage2_large(pl, four(ua, va, ta, wap), dtype, B4, B3, st);
   // C = G^-1 B4 and the four zonal means ub vb thetab wapb -> zb[0..3]
   if ((rc = launch_solve(pl, B4, 4, pl->D, pl->C4.d(), pl->zb.d(), st))) return rc;
@@ -2621,6 +2853,7 @@ int temx_tem_stage2_from_sums(temx_plan* pl, const double* B4, double* B3, void*
     return fail(TEMX_ESTATE, "no class sums: temx_tem_stage1 must precede temx_tem_stage2_from_sums");
   HIPCHK(hipSetDevice(pl->device));
   hipStream_t st = S_(stream);
+  if (!tail_is_whole(pl)) return fail(TEMX_ESTATE, "a time-sliced tail ran since the last temx_tem_stage1");
   if ((rc = launch_solve(pl, B4, 4, pl->D, pl->C4.d(), pl->zb.d(), st))) return rc;
   pl->c4_valid = true;
   if (pl->large) {
@@ -2643,26 +2876,141 @@ int temx_tem_stage3(temx_plan* pl, const double* B3, double* results, double* zo
   if (rc) return rc;
   if (!B3 || !results) return fail(TEMX_EINVAL, "null argument");
   HIPCHK(hipSetDevice(pl->device));
-  hipStream_t st = S_(stream);
-  const int64_t MD = (int64_t)pl->M * pl->D;
+  if (!tail_is_whole(pl))
+    return fail(TEMX_ESTATE, "the zonal means in the plan are those of a time slice (temx_tem_os_tail); stage 3 needs a "
+                             "temx_tem_stage2 / stage2_from_sums on the whole run first");
+  return tem_stage3_impl(pl, B3, results, zonal, S_(stream));
+}
+
+// flux zonal means, derivatives, psi, integral and the ten diagnostics for the snapshots of the tail (pl->tnt of them;
+// zb[0..3] hold the zonal means of the four fields for the same snapshots)
+static int tem_stage3_impl(temx_plan* pl, const double* B3, double* results, double* zonal, hipStream_t st) {
+  int rc;
+  const int64_t Dt = pl->tD, nts = pl->tnt;
+  const int64_t MD = (int64_t)pl->M * Dt;
   // flux zonal means upvpb upwappb vptpb -> zb[4..6]
-  if ((rc = launch_solve(pl, B3, 3, pl->D, nullptr, pl->zb.d() + 4 * MD, st))) return rc;
+  if ((rc = launch_solve(pl, B3, 3, Dt, nullptr, pl->zb.d() + 4 * MD, st))) return rc;
   // int_vbdp -> zb[7]: by a wavefront scan; inside the epilogue only for short columns on small zonal grids
   // (measured: at nlev = 72 the O(nlev) loop per point costs what the extra launch saves, at 128 more)
   EpiTables tb{pl->p.d(), pl->pg.d(), pl->lg.d(), pl->coslat.d(), pl->fcor.d()};
   if (pl->nlev > 40 || MD > ((int64_t)1 << 17)) {
-    const int64_t ncols = (int64_t)pl->M * pl->nt;
+    const int64_t ncols = (int64_t)pl->M * nts;
     hipLaunchKernelGGL(pint_scan_kernel, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st, pl->zb.d() + 1 * MD,
-                       pl->p.d(), pl->M, pl->nlev, pl->nt, pl->zb.d() + 7 * MD);
+                       pl->p.d(), pl->M, pl->nlev, nts, pl->zb.d() + 7 * MD);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(tem_epilogue_kernel<false>, dim3((unsigned)((MD + 255) / 256)), dim3(256), 0, st, pl->zb.d(),
-                       pl->M, pl->nlev, pl->nt, tb, pl->p0, results, zonal);
+                       pl->M, pl->nlev, nts, tb, pl->p0, results, zonal);
   } else {
     hipLaunchKernelGGL(tem_epilogue_kernel<true>, dim3((unsigned)((MD + 255) / 256)), dim3(256), 0, st, pl->zb.d(),
-                       pl->M, pl->nlev, pl->nt, tb, pl->p0, results, zonal);
+                       pl->M, pl->nlev, nts, tb, pl->p0, results, zonal);
   }
   HIPCHK(hipGetLastError());
   return TEMX_OK;
+}
+
+// ---- the single sweep in three steps (ncol-sharded jobs exchange between them; see include/temx.h) -----------
+static int os_ready(temx_plan* pl) {
+  int rc = tem_ready(pl);
+  if (rc) return rc;
+  if (!pl->os_on) return fail(TEMX_ESTATE, "the plan does not run the single-sweep form (temx_plan_single_sweep)");
+  if (pl->os_need_global)
+    return fail(TEMX_ESTATE, "ncol-sharded single sweep: temx_plan_set_os_matrices with the all-reduced TEMX_MAT_GX / TEMX_MAT_GSUB first");
+  return TEMX_OK;
+}
+static int slices_ok(const temx_plan* pl, int nslices) {
+  if (nslices < 1 || nslices > pl->nt)
+    return fail(TEMX_EINVAL, "nslices = %d: a time-sliced tail needs 1 <= nslices <= nt = %lld", nslices, (long long)pl->nt);
+  return TEMX_OK;
+}
+
+int temx_tem_os_prepass(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap, int dtype,
+                        double* As, void* stream) {
+  int rc = os_ready(pl);
+  if (rc) return rc;
+  if (!ua || !va || !ta || !wap || !As) return fail(TEMX_EINVAL, "null argument");
+  if (dtype != TEMX_F64 && dtype != TEMX_F32) return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
+  HIPCHK(hipSetDevice(pl->device));
+  return os_prepass(pl, four(ua, va, ta, wap), dtype, As, S_(stream));
+}
+
+int temx_tem_os_sweep(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap, int dtype,
+                      const double* As, int nslices, double* proj, void* stream) {
+  int rc = os_ready(pl);
+  if (rc) return rc;
+  if (!ua || !va || !ta || !wap || !As || !proj) return fail(TEMX_EINVAL, "null argument");
+  if (dtype != TEMX_F64 && dtype != TEMX_F32) return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
+  if ((rc = slices_ok(pl, nslices))) return rc;
+  HIPCHK(hipSetDevice(pl->device));
+  return os_sweep(pl, four(ua, va, ta, wap), dtype, As, nslices, proj, S_(stream));
+}
+
+int temx_tem_os_tail(temx_plan* pl, const double* proj_slice, int64_t t0, int64_t nts, double* results, double* zonal,
+                     void* stream) {
+  int rc = os_ready(pl);
+  if (rc) return rc;
+  if (!proj_slice || !results) return fail(TEMX_EINVAL, "null argument");
+  if (t0 < 0 || nts < 1 || t0 + nts > pl->nt)
+    return fail(TEMX_EINVAL, "snapshots [%lld, %lld) are not inside the run (nt = %lld)", (long long)t0, (long long)(t0 + nts), (long long)pl->nt);
+  HIPCHK(hipSetDevice(pl->device));
+  return os_tail(pl, proj_slice, t0, nts, results, zonal, S_(stream));
+}
+
+int temx_tracer_os_prepass(temx_plan* pl, const void* q, const void* va, const void* wap, int dtype, double* Asq, void* stream) {
+  int rc = os_ready(pl);
+  if (rc) return rc;
+  if (!q || !va || !wap || !Asq) return fail(TEMX_EINVAL, "null argument");
+  if (dtype != TEMX_F64 && dtype != TEMX_F32) return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
+  HIPCHK(hipSetDevice(pl->device));
+  return tracer_os_prepass(pl, four(q, va, wap, nullptr), dtype, Asq, S_(stream));
+}
+
+int temx_tracer_os_sweep(temx_plan* pl, const void* q, const void* va, const void* wap, int dtype, const double* Asq,
+                         int nslices, double* projq, void* stream) {
+  int rc = os_ready(pl);
+  if (rc) return rc;
+  if (!q || !va || !wap || !Asq || !projq) return fail(TEMX_EINVAL, "null argument");
+  if (dtype != TEMX_F64 && dtype != TEMX_F32) return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
+  if ((rc = slices_ok(pl, nslices))) return rc;
+  HIPCHK(hipSetDevice(pl->device));
+  return tracer_os_sweep(pl, four(q, va, wap, nullptr), dtype, Asq, nslices, projq, S_(stream));
+}
+
+int temx_tracer_os_tail(temx_plan* pl, const double* projq_slice, double* tres, double* tzon, void* stream) {
+  int rc = os_ready(pl);
+  if (rc) return rc;
+  if (!projq_slice || !tres) return fail(TEMX_EINVAL, "null argument");
+  if (!pl->os_valid || !pl->c4_valid)
+    return fail(TEMX_ESTATE, "the tracer's tail needs the state of a temx_tem_os_tail on the same snapshots");
+  HIPCHK(hipSetDevice(pl->device));
+  if ((rc = tracer_os_ws(pl))) return rc;
+  return tracer_os_tail(pl, projq_slice, tres, tzon, S_(stream));
+}
+
+// stages 2b + 3 on a time slice, from raw sums of any form of the sweeps: B4s [4][K][nlev][nts], B3s [3][K][nlev][nts]
+int temx_tem_tail_from_sums(temx_plan* pl, const double* B4s, const double* B3s, int64_t t0, int64_t nts, double* results,
+                            double* zonal, void* stream) {
+  int rc = tem_ready(pl);
+  if (rc) return rc;
+  if (!B4s || !B3s || !results) return fail(TEMX_EINVAL, "null argument");
+  if (t0 < 0 || nts < 1 || t0 + nts > pl->nt)
+    return fail(TEMX_EINVAL, "snapshots [%lld, %lld) are not inside the run (nt = %lld)", (long long)t0, (long long)(t0 + nts), (long long)pl->nt);
+  HIPCHK(hipSetDevice(pl->device));
+  hipStream_t st = S_(stream);
+  set_tail(pl, t0, nts);
+  pl->c4_valid = pl->os_valid = false;                        // zb describes the slice from here on
+  if ((rc = launch_solve(pl, B4s, 4, pl->tD, nullptr, pl->zb.d(), st))) return rc;
+  return tem_stage3_impl(pl, B3s, results, zonal, st);
+}
+
+// Cut rows of [nlev][nt] columns into the time slices a reduce-scatter wants: out[w][row][lev][t - t0(w)], slice w
+// padded to rows * nlev * ceil(nt / nslices) doubles (kernels.hpp, SliceMap).
+int temx_time_slices(temx_plan* pl, const double* B, int64_t rows, int nslices, double* out, void* stream) {
+  int rc = tem_ready(pl);
+  if (rc) return rc;
+  if (!B || !out || rows < 1) return fail(TEMX_EINVAL, "bad argument");
+  if ((rc = slices_ok(pl, nslices))) return rc;
+  HIPCHK(hipSetDevice(pl->device));
+  return launch_reduce(pl, B, 1, rows * pl->D, out, S_(stream), -1, nullptr, slice_map(pl, nslices, rows, 0));
 }
 
 int temx_tem_run(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap,
@@ -2670,6 +3018,7 @@ int temx_tem_run(temx_plan* pl, const void* ua, const void* va, const void* ta, 
   int rc = tem_ready(pl);
   if (rc) return rc;
   if (os_active(pl, dtype)) {
+    if ((rc = os_ready(pl))) return rc;
     if (!ua || !va || !ta || !wap || !results) return fail(TEMX_EINVAL, "null argument");
     if (dtype != TEMX_F64 && dtype != TEMX_F32) return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
     HIPCHK(hipSetDevice(pl->device));
@@ -2690,6 +3039,7 @@ int temx_tem_eddy(temx_plan* pl, const void* ua, const void* va, const void* ta,
   if (rc) return rc;
   if (!ua || !va || !ta || !wap || !eddy_ptrs_host) return fail(TEMX_EINVAL, "null argument");
   HIPCHK(hipSetDevice(pl->device));
+  if (!tail_is_whole(pl)) return fail(TEMX_ESTATE, "the plan holds the coefficients of a time slice (temx_tem_os_tail), not of the whole run");
   EddyOut eo;
   for (int i = 0; i < TEMX_NEDDY; ++i) eo.p[i] = eddy_ptrs_host[i];
   if (unfused_stage2(pl)) {
@@ -2710,6 +3060,7 @@ int temx_tem_eddy_rows(temx_plan* pl, const void* ua, const void* va, const void
                 (long long)row0, (long long)(row0 + nrows));
   if (dtype != TEMX_F64 && dtype != TEMX_F32) return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
   HIPCHK(hipSetDevice(pl->device));
+  if (!tail_is_whole(pl)) return fail(TEMX_ESTATE, "the plan holds the coefficients of a time slice (temx_tem_os_tail), not of the whole run");
   hipStream_t st = S_(stream);
   const int64_t D = pl->D, nd = nrows * D;
   // native zonal means of the rows (coefficients of the last temx_tem_stage2), then elementwise eddies
@@ -2765,6 +3116,7 @@ int temx_tracer_stage2(temx_plan* pl, const void* q, const void* va, const void*
   if (rc) return rc;
   if (!q || !va || !wap || !Bq || !Bq2) return fail(TEMX_EINVAL, "null argument");
   HIPCHK(hipSetDevice(pl->device));
+  if (!tail_is_whole(pl)) return fail(TEMX_ESTATE, "the plan holds the coefficients of a time slice (temx_tem_os_tail), not of the whole run");
   if ((rc = tracer_ws(pl))) return rc;
   hipStream_t st = S_(stream);
   const size_t slab = (size_t)pl->K4 * pl->D * 8;
@@ -2798,13 +3150,19 @@ int temx_tracer_stage3(temx_plan* pl, const double* Bq2, double* tres, double* t
   if (rc) return rc;
   if (!Bq2 || !tres) return fail(TEMX_EINVAL, "null argument");
   if (!pl->tz.p) return fail(TEMX_ESTATE, "temx_tracer_stage2 has not been called");
+  if (!tail_is_whole(pl)) return fail(TEMX_ESTATE, "the plan holds the zonal means of a time slice (temx_tem_os_tail)");
   HIPCHK(hipSetDevice(pl->device));
-  hipStream_t st = S_(stream);
-  const int64_t MD = (int64_t)pl->M * pl->D;
-  if ((rc = launch_solve(pl, Bq2, 2, pl->D, nullptr, pl->tz.d() + MD, st))) return rc;   // qpvpb, qpwappb
+  return tracer_stage3_impl(pl, Bq2, tres, tzon, S_(stream));
+}
+
+static int tracer_stage3_impl(temx_plan* pl, const double* Bq2, double* tres, double* tzon, hipStream_t st) {
+  int rc;
+  const int64_t Dt = pl->tD;
+  const int64_t MD = (int64_t)pl->M * Dt;
+  if ((rc = launch_solve(pl, Bq2, 2, Dt, nullptr, pl->tz.d() + MD, st))) return rc;   // qpvpb, qpwappb
   EpiTables tb{pl->p.d(), pl->pg.d(), pl->lg.d(), pl->coslat.d(), pl->fcor.d()};
   hipLaunchKernelGGL(tracer_epilogue_kernel, dim3((unsigned)((MD + 255) / 256)), dim3(256), 0, st, pl->zb.d(),
-                     pl->tz.d(), pl->M, pl->nlev, pl->nt, tb, pl->p0, tres, tzon);
+                     pl->tz.d(), pl->M, pl->nlev, pl->tnt, tb, pl->p0, tres, tzon);
   HIPCHK(hipGetLastError());
   return TEMX_OK;
 }
@@ -2847,6 +3205,7 @@ int temx_tracer_stage2_from_sums(temx_plan* pl, const double* Bq, double* Bq2, v
   if (!tracer_one_pass(pl) || !pl->tq_valid)
     return fail(TEMX_ESTATE, "no tracer class sums: temx_tracer_stage1_sums must precede temx_tracer_stage2_from_sums");
   HIPCHK(hipSetDevice(pl->device));
+  if (!tail_is_whole(pl)) return fail(TEMX_ESTATE, "the plan holds the coefficients of a time slice (temx_tem_os_tail), not of the whole run");
   hipStream_t st = S_(stream);
   const size_t slab = (size_t)pl->K4 * pl->D * 8;
   // coefficients: Ct = (C_q, C_v, C_w); qb -> tz[0]
@@ -2878,6 +3237,7 @@ int temx_tem_tracer_stage1(temx_plan* pl, const void* ua, const void* va, const 
   if ((rc = pl->csq.ensure((size_t)pl->cgroups * sp.ndt * 2 * 64 * 8))) return rc;
   if ((rc = pl->Pq2.ensure((size_t)2 * KD * 8))) return rc;
   if ((rc = pl->partial.ensure(std::max((size_t)sp.nsplit * 10 * KD * 8, pl->partial.bytes)))) return rc;
+  set_tail(pl, 0, pl->nt);
   pl->op_valid = pl->c4_valid = pl->tq_valid = pl->os_valid = false;
   FieldPtrs<5> fp;
   fp.p[0] = ua; fp.p[1] = va; fp.p[2] = ta; fp.p[3] = wap; fp.p[4] = q;
@@ -2921,7 +3281,7 @@ int temx_tracer_run(temx_plan* pl, const void* q, const void* va, const void* wa
                     double* tres, double* tzon, void* stream) {
   int rc = tem_ready(pl);
   if (rc) return rc;
-  if (pl->os_valid && pl->c4_valid && os_active(pl, dtype)) {   // after a single-sweep TEM run: the tracer's single sweep
+  if (pl->os_valid && pl->c4_valid && tail_is_whole(pl) && os_active(pl, dtype)) {   // after a single-sweep TEM run: the tracer's single sweep
     if (!q || !va || !wap || !tres) return fail(TEMX_EINVAL, "null argument");
     if (dtype != TEMX_F64 && dtype != TEMX_F32) return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
     HIPCHK(hipSetDevice(pl->device));
@@ -2931,8 +3291,7 @@ int temx_tracer_run(temx_plan* pl, const void* q, const void* va, const void* wa
   // The one-pass form reads (q, v, omega) once instead of q + (q, v, omega), but its sweep shares a SIMD
   // with fewer waves than the two-pass kernels: measured on ne120 x 72 x 30 it is no faster (10.2 ms
   // against 9.6 ms), so the two-pass stages stay the default and TEMX_TRACER_ONE_PASS=1 selects it.
-  static const bool want_one = [] { const char* e = getenv("TEMX_TRACER_ONE_PASS"); return e && e[0] == '1'; }();
-  if (want_one && tracer_one_pass(pl)) {
+  if (tracer_one_pass_wanted(pl) && tracer_one_pass(pl)) {
     if ((rc = temx_tracer_stage1_sums(pl, q, va, wap, dtype, pl->Bq.d(), stream))) return rc;
     if ((rc = temx_tracer_stage2_from_sums(pl, pl->Bq.d(), pl->Bq2.d(), stream))) return rc;
     return temx_tracer_stage3(pl, pl->Bq2.d(), tres, tzon, stream);
@@ -2949,6 +3308,7 @@ int temx_tracer_eddy(temx_plan* pl, const void* q, const void* va, const void* w
   if (!q || !va || !wap || !ptrs3_host) return fail(TEMX_EINVAL, "null argument");
   if (!pl->Ct.p) return fail(TEMX_ESTATE, "temx_tracer_stage2 has not been called");
   HIPCHK(hipSetDevice(pl->device));
+  if (!tail_is_whole(pl)) return fail(TEMX_ESTATE, "the plan holds the coefficients of a time slice (temx_tem_os_tail), not of the whole run");
   EddyOut eo{};
   eo.p[0] = ptrs3_host[0];
   eo.p[4] = ptrs3_host[1];

@@ -26,7 +26,8 @@ def _dbl(a):
 class Plan:
     """One plan per (device, native grid, output latitudes, L).  See include/temx.h."""
 
-    def __init__(self, lat_deg, lat_out_deg, L, device=0, defer_finalize=False, symmetry=True, classes=True):
+    def __init__(self, lat_deg, lat_out_deg, L, device=0, defer_finalize=False, symmetry=True, classes=True, qr=True,
+                 form=None):
         self._h = C.c_void_p()
         self.lib = _lib.load()
         if isinstance(device, torch.device):
@@ -41,7 +42,10 @@ class Plan:
         check(self.lib.temx_plan_create(C.byref(self._h), self.device_index, self.N, self.L, self.M,
                                         plat, plat_out, (_lib.DEFER_FINALIZE if defer_finalize else 0)
                                         | (0 if symmetry else _lib.NO_SYMMETRY)
-                                        | (0 if classes else _lib.NO_CLASSES)))
+                                        | (0 if classes else _lib.NO_CLASSES)
+                                        | (0 if qr else _lib.NO_QR)))
+        if form is not None:
+            self.configure(form=form)
 
     @property
     def paired(self):
@@ -66,10 +70,32 @@ class Plan:
 
     @property
     def tracer_one_pass(self):
-        """True when tracer runs should take the one-pass stages (``one_pass`` and TEMX_TRACER_ONE_PASS=1;
+        """True when tracer runs should take the one-pass stages (``one_pass`` and the option / TEMX_TRACER_ONE_PASS=1;
         the two-pass tracer stages measured faster, see include/temx.h)."""
-        import os
-        return self.one_pass and os.environ.get("TEMX_TRACER_ONE_PASS") == "1"
+        return self.one_pass and self.option(_lib.OPT_TRACER_ONE_PASS) == 1
+
+    def configure(self, form=None, os_map=None, op_map=None, os_subsample=None, tracer_one_pass=None,
+                  single_sweep_min_groups=None):
+        """Path selection (temx_plan_configure); ``set_tem`` must follow.  ``form``: a key of ``_lib.FORMS``
+        ("auto", "two-pass", "class-sums", "single-sweep", "no-single-sweep"); ``os_map`` / ``op_map``:
+        "row" or "tile" (lane map of the loads of the single sweep / of sweep 1 of the class-sum form)."""
+        def put(opt, val):
+            check(self.lib.temx_plan_configure(self._h, opt, int(val)))
+        if form is not None:
+            put(_lib.OPT_FORM, _lib.FORMS[form] if isinstance(form, str) else form)
+        for opt, val in ((_lib.OPT_OS_MAP, os_map), (_lib.OPT_OP_MAP, op_map)):
+            if val is not None:
+                put(opt, {"row": 0, "tile": 1}[val] if isinstance(val, str) else val)
+        if os_subsample is not None:
+            put(_lib.OPT_OS_SUBSAMPLE, os_subsample)
+        if tracer_one_pass is not None:
+            put(_lib.OPT_TRACER_ONE_PASS, 1 if tracer_one_pass else 0)
+        if single_sweep_min_groups is not None:
+            put(_lib.OPT_SINGLE_SWEEP_MIN_GROUPS, single_sweep_min_groups)
+        self.nlev = self.nt = self.D = None
+
+    def option(self, opt):
+        return int(self.lib.temx_plan_option(self._h, int(opt)))
 
     # ---- lifetime ----
     def close(self):
@@ -128,6 +154,7 @@ class Plan:
         shape = {_lib.MAT_Y0: (self.N, self.K), _lib.MAT_Y0P: (self.M, self.K),
                  _lib.MAT_GRAM: (self.K, self.K), _lib.MAT_GINV: (self.K, self.K),
                  _lib.MAT_GRAM2: (self.K, self.K),
+                 _lib.MAT_GX: (self.K, self.KX), _lib.MAT_GSUB: (self.KR, self.KR),
                  _lib.MAT_Y0INV: (self.K, self.N)}[which]
         out = torch.empty(shape, dtype=torch.float64, device=self.device)
         check(self.lib.temx_get_matrix(self._h, which, _ptr(out), self._stream()))
@@ -164,6 +191,7 @@ class Plan:
         assert p.size == nlev
         check(self.lib.temx_plan_set_tem(self._h, int(nlev), int(nt), pp, float(p0)))
         self.nlev, self.nt, self.D = int(nlev), int(nt), int(nlev) * int(nt)
+        self.tem_args = (int(nlev), int(nt), p.copy(), float(p0))
 
     def _four(self, ua, va, ta, wap):
         if self.D is None:
@@ -187,6 +215,96 @@ class Plan:
         res, zon = out if out is not None else self._alloc_results(want_zonal)
         check(self.lib.temx_tem_run(self._h, _ptr(u), _ptr(v), _ptr(t), _ptr(w), dt, _ptr(res),
                                     _ptr(zon) if zon is not None else None, self._stream()))
+        return res, zon
+
+    # ---- the single sweep in three steps (ncol-sharded jobs exchange between them; include/temx.h) ----
+    @property
+    def KX(self):
+        return 2 * self.L + 1
+
+    @property
+    def KR(self):
+        return min(16, self.K)
+
+    @property
+    def os_rows(self):
+        """Rows of the projections the single sweep hands over: four fields to degree 2L, three products to degree L."""
+        return 4 * self.KX + 3 * self.K
+
+    def set_os_matrices(self, Gx, Gsub):
+        gx, pgx = _dbl(Gx)
+        gs, pgs = _dbl(Gsub)
+        assert gx.shape == (self.K, self.KX) and gs.shape == (self.KR, self.KR)
+        check(self.lib.temx_plan_set_os_matrices(self._h, pgx, pgs))
+
+    def _sliced(self, rows, nslices):
+        ntmax = -(-self.nt // nslices)
+        shape = (rows, self.nlev, self.nt) if nslices == 1 else (nslices, rows * self.nlev * ntmax)
+        return torch.zeros(shape, dtype=torch.float64, device=self.device)
+
+    def tem_os_prepass(self, ua, va, ta, wap, out=None):
+        (u, v, t, w), dt = self._four(ua, va, ta, wap)
+        As = out if out is not None else torch.empty((4, self.KR, self.D), dtype=torch.float64, device=self.device)
+        check(self.lib.temx_tem_os_prepass(self._h, _ptr(u), _ptr(v), _ptr(t), _ptr(w), dt, _ptr(As), self._stream()))
+        return As
+
+    def tem_os_sweep(self, ua, va, ta, wap, As, nslices=1, out=None):
+        """-> the projections, whole ([rows][nlev][nt]) or as ``nslices`` time slices ([nslices][chunk]: the input of
+        ``reduce_scatter_tensor``; slice w holds rows of nlev x ntw(w) columns packed at its start)."""
+        (u, v, t, w), dt = self._four(ua, va, ta, wap)
+        proj = out if out is not None else self._sliced(self.os_rows, nslices)
+        check(self.lib.temx_tem_os_sweep(self._h, _ptr(u), _ptr(v), _ptr(t), _ptr(w), dt, _ptr(As.contiguous()),
+                                         int(nslices), _ptr(proj), self._stream()))
+        return proj
+
+    def tem_os_tail(self, proj_slice, t0=0, nts=None, want_zonal=False, out=None):
+        nts = self.nt if nts is None else int(nts)
+        res = out if out is not None else torch.empty((len(_lib.RESULT_NAMES), self.M, self.nlev, nts),
+                                                      dtype=torch.float64, device=self.device)
+        zon = None
+        if want_zonal:
+            zon = torch.empty((len(_lib.ZONAL_NAMES), self.M, self.nlev, nts), dtype=torch.float64, device=self.device)
+        check(self.lib.temx_tem_os_tail(self._h, _ptr(proj_slice), int(t0), nts, _ptr(res),
+                                        _ptr(zon) if zon is not None else None, self._stream()))
+        return res, zon
+
+    def tracer_os_prepass(self, q, va, wap):
+        (qq, v, w), dt = self._three(q, va, wap)
+        Asq = torch.empty((self.KR, self.D), dtype=torch.float64, device=self.device)
+        check(self.lib.temx_tracer_os_prepass(self._h, _ptr(qq), _ptr(v), _ptr(w), dt, _ptr(Asq), self._stream()))
+        return Asq
+
+    def tracer_os_sweep(self, q, va, wap, Asq, nslices=1):
+        (qq, v, w), dt = self._three(q, va, wap)
+        projq = self._sliced(self.KX + 2 * self.K, nslices)
+        check(self.lib.temx_tracer_os_sweep(self._h, _ptr(qq), _ptr(v), _ptr(w), dt, _ptr(Asq.contiguous()), int(nslices),
+                                            _ptr(projq), self._stream()))
+        return projq
+
+    def tracer_os_tail(self, projq_slice, nts, want_zonal=False):
+        tres = torch.empty((len(_lib.TRACER_RESULT_NAMES), self.M, self.nlev, nts), dtype=torch.float64, device=self.device)
+        tzon = None
+        if want_zonal:
+            tzon = torch.empty((len(_lib.TRACER_ZONAL_NAMES), self.M, self.nlev, nts), dtype=torch.float64, device=self.device)
+        check(self.lib.temx_tracer_os_tail(self._h, _ptr(projq_slice), _ptr(tres), _ptr(tzon) if tzon is not None else None,
+                                           self._stream()))
+        return tres, tzon
+
+    def time_slices(self, B, nslices):
+        """Rows of [nlev][nt] columns -> the reduce-scatter layout [nslices][chunk] (temx_time_slices)."""
+        B = B.contiguous()
+        rows = B.numel() // self.D
+        out = self._sliced(rows, nslices)
+        check(self.lib.temx_time_slices(self._h, _ptr(B), rows, int(nslices), _ptr(out), self._stream()))
+        return out
+
+    def tem_tail_from_sums(self, B4s, B3s, t0, nts, want_zonal=False):
+        res = torch.empty((len(_lib.RESULT_NAMES), self.M, self.nlev, nts), dtype=torch.float64, device=self.device)
+        zon = None
+        if want_zonal:
+            zon = torch.empty((len(_lib.ZONAL_NAMES), self.M, self.nlev, nts), dtype=torch.float64, device=self.device)
+        check(self.lib.temx_tem_tail_from_sums(self._h, _ptr(B4s), _ptr(B3s), int(t0), int(nts), _ptr(res),
+                                               _ptr(zon) if zon is not None else None, self._stream()))
         return res, zon
 
     def tem_stage1(self, ua, va, ta, wap):

@@ -22,7 +22,7 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
-MAT_GRAM, MAT_GRAM2 = 2, 5
+MAT_GRAM, MAT_GRAM2, MAT_GX, MAT_GSUB = 2, 5, 6, 7
 
 
 def shard_bounds(n, world, rank):
@@ -67,15 +67,47 @@ def allreduce_sum_(t, group=None):
     return t
 
 
+def reduce_scatter_sum(chunks, group=None, out=None):
+    """``chunks`` is ``[world][n]`` (contiguous): rank w receives the sum over the ranks of chunk w (``[n]``).
+    RCCL: one ``reduce_scatter_tensor``; back ends without it (gloo on device tensors) all-reduce and slice."""
+    w = _world(group)
+    if w == 1:
+        return chunks.reshape(-1)
+    assert chunks.shape[0] == w and chunks.is_contiguous()
+    rank = dist.get_rank(group)
+    if dist.get_backend(group) == "nccl":
+        if out is None:
+            out = torch.empty(chunks.shape[1:], dtype=chunks.dtype, device=chunks.device)
+        dist.reduce_scatter_tensor(out, chunks, op=dist.ReduceOp.SUM, group=group)
+        return out.reshape(-1)
+    dist.all_reduce(chunks, op=dist.ReduceOp.SUM, group=group)
+    return chunks[rank].reshape(-1)
+
+
 class NcolShardedTEM:
     """TEM pipeline over this rank's block of native columns.
 
-    ``backend`` is a plan created over the rank's own latitudes with ``defer_finalize=True``.
-    """
+    ``backend`` is a plan created over the rank's own latitudes with ``defer_finalize=True``.  Two forms of a step:
 
-    def __init__(self, backend, group=None):
+    * **time-sliced tail** (the plans run the single sweep, ``nt >= world``): everything after the zonal sums acts
+      along latitude and pressure only, so the sums are exchanged by a REDUCE-SCATTER OVER TIME and each rank finishes
+      the snapshots it receives -- nothing of the tail is replicated.  Per step: all-reduce of the reference
+      pre-pass sums (4 x 16 x D doubles), one reduce-scatter of the projections ((4 (2L+1) + 3 (L+1)) x D doubles, an
+      eighth of it arriving per rank at world 8).  ``run`` returns this rank's snapshots
+      ``[..][M][nlev][t0:t1]`` (``shard_bounds(nt, world, rank)``; ``gather_time`` assembles the whole);
+    * **replicated tail** (any other plan): all-reduce of the [4][K][D] sums, stage 2, all-reduce of the
+      [3][K][D] sums, every rank solves and evaluates the zonal-grid epilogue redundantly; ``run`` returns the whole.
+
+    ``tail``: "auto" (sliced when possible), "replicated", or "sliced" (raise when not possible)."""
+
+    def __init__(self, backend, group=None, tail="auto"):
         self.backend = backend
         self.group = group
+        self.world = _world(group)
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.tail = tail
+        self._sliced = None                            # decided at the first step (the plan's TEM shape is set later)
+        self._buf = {}
         G = backend.matrix(MAT_GRAM)
         allreduce_sum_(G, group)                       # (i) Gram matrix, K x K, once
         backend.finalize(G.detach().cpu().numpy())
@@ -84,8 +116,61 @@ class NcolShardedTEM:
             allreduce_sum_(G2, group)
             backend.refine(G2.detach().cpu().numpy())
 
+    def set_tem(self, nlev, nt, p_pa, p0=101325.0):
+        """``backend.set_tem`` with the reference subsample of the single sweep spread over the ranks, followed by
+        the plan-build collectives of the time-sliced form.  (Calling ``backend.set_tem`` directly works too: the
+        collectives then run at the first step.)"""
+        be = self.backend
+        if hasattr(be, "configure") and self.tail != "replicated":
+            be.configure(os_subsample=max(12, -(-96 // self.world)))
+        be.set_tem(nlev, nt, p_pa, p0)
+        self._decide()
+
+    def _decide(self):
+        """Collective: do all ranks run the single sweep, and does the time axis cut into ``world`` slices?"""
+        be = self.backend
+        ok = (self.tail != "replicated" and bool(getattr(be, "single_sweep", False))
+              and getattr(be, "nt", 0) is not None and int(getattr(be, "nt", 0) or 0) >= self.world)
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64,
+                            device=getattr(be, "device", torch.device("cpu")))
+        if self.world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        self._sliced = bool(flag.item() > 0.5)
+        if self._sliced:
+            # the two matrices of the single sweep that sum over the rows (temx_plan_set_os_matrices)
+            Gx, Gs = be.matrix(MAT_GX), be.matrix(MAT_GSUB)
+            allreduce_sum_(Gx, self.group)
+            allreduce_sum_(Gs, self.group)
+            be.set_os_matrices(Gx.detach().cpu().numpy(), Gs.detach().cpu().numpy())
+        elif self.tail == "sliced":
+            raise RuntimeError("NcolShardedTEM(tail='sliced'): not every rank's plan runs the single sweep, or nt < world")
+        elif bool(getattr(be, "single_sweep", False)):
+            # some rank cannot: all ranks take the class-sum form (its stage interface is what the replicated flow drives)
+            args = be.tem_args
+            be.configure(form="no-single-sweep")
+            be.set_tem(*args)
+        return self._sliced
+
+    @property
+    def sliced(self):
+        return bool(self._sliced)
+
+    def my_snapshots(self):
+        """(t0, t1): the snapshots this rank's results describe (the whole run with a replicated tail)."""
+        nt = int(self.backend.nt)
+        return shard_bounds(nt, self.world, self.rank) if self._sliced else (0, nt)
+
     def run(self, ua, va, ta, wap, want_zonal=False):
         be = self.backend
+        if self._sliced is None:
+            self._decide()
+        if self._sliced:
+            As = be.tem_os_prepass(ua, va, ta, wap)
+            allreduce_sum_(As, self.group)             # (ii) reference pre-pass sums [4][KR][D], one message
+            proj = be.tem_os_sweep(ua, va, ta, wap, As, nslices=self.world)
+            mine = reduce_scatter_sum(proj, self.group)    # (iii) projections, one time slice per rank
+            t0, t1 = shard_bounds(int(be.nt), self.world, self.rank)
+            return be.tem_os_tail(mine, t0, t1 - t0, want_zonal)
         B4 = be.tem_stage1(ua, va, ta, wap)
         allreduce_sum_(B4, self.group)                 # (ii) [4][K][D] zonal sums, one message
         # one-pass class path: stage 2 works from the class sums stage 1 just stored for these fields
@@ -97,9 +182,17 @@ class NcolShardedTEM:
         return be.tem_stage3(B3, want_zonal)
 
     def run_tracer(self, q, va, wap, want_zonal=False):
-        """Tracer TEM for one tracer; call after ``run`` on the same fields (two more all-reduces:
-        [K][D] sums of q, [2][K][D] sums of q'v', q'w')."""
+        """Tracer TEM for one tracer; call after ``run`` on the same fields.  Time-sliced tail: all-reduce of q's
+        pre-pass sums, reduce-scatter of its projections; otherwise two more all-reduces ([K][D] sums of q,
+        [2][K][D] sums of q'v', q'w')."""
         be = self.backend
+        if self._sliced:
+            Asq = be.tracer_os_prepass(q, va, wap)
+            allreduce_sum_(Asq, self.group)
+            projq = be.tracer_os_sweep(q, va, wap, Asq, nslices=self.world)
+            mine = reduce_scatter_sum(projq, self.group)
+            t0, t1 = shard_bounds(int(be.nt), self.world, self.rank)
+            return be.tracer_os_tail(mine, t1 - t0, want_zonal)
         if getattr(be, "tracer_one_pass", False):      # (q, v, omega) read once, see include/temx.h
             Bq = be.tracer_stage1_sums(q, va, wap)
             allreduce_sum_(Bq, self.group)

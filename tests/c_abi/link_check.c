@@ -15,7 +15,11 @@ int main(void) {
       (const void*)temx_tracer_stage3, (const void*)temx_tracer_stage1_sums, (const void*)temx_tracer_stage2_from_sums,
       (const void*)temx_tracer_run, (const void*)temx_tem_tracer_stage1, (const void*)temx_tem_tracer_run, (const void*)temx_tracer_eddy,
       (const void*)temx_status, (const void*)temx_synth_fields, (const void*)temx_mfma_f64_peak,
-      (const void*)temx_kernel_timing, (const void*)temx_kernel_timing_read};
+      (const void*)temx_kernel_timing, (const void*)temx_kernel_timing_read,
+      (const void*)temx_plan_configure, (const void*)temx_plan_option, (const void*)temx_plan_set_os_matrices,
+      (const void*)temx_tem_os_prepass, (const void*)temx_tem_os_sweep, (const void*)temx_tem_os_tail,
+      (const void*)temx_tracer_os_prepass, (const void*)temx_tracer_os_sweep, (const void*)temx_tracer_os_tail,
+      (const void*)temx_tem_tail_from_sums, (const void*)temx_time_slices};
   unsigned n = (unsigned)(sizeof(syms) / sizeof(syms[0])), i, ok = 0;
   for (i = 0; i < n; ++i) ok += syms[i] != 0;
   /* argument checking happens before any device call: a null plan is an error, not a crash */
