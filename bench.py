@@ -140,11 +140,12 @@ def main():
                     help="do not use the latitude-class sweeps (mirror-paired sweeps on a symmetric grid)")
     ap.add_argument("--no-extras", action="store_true",
                     help="N > 1: skip the legs reported beside the metric (time-sharded configs[2], weak scaling)")
-    ap.add_argument("--also", default="ne30x72x1,ne30x72x91,ne240x128x1:f32,ne120x72x30:f32,ne120x72x30:f64:generic,ne120x72x30:f64:shard1of8",
+    ap.add_argument("--also", default="ne30x72x1,ne30x72x91,ne240x128x1:f32,ne120x72x30:f32,ne120x72x30:f64:generic,ne120x72x30:f64:shard1of8,ne120x72x4",
                     help="comma list of the other BASELINE.json shapes, timed after the main one at N=1 "
-                         "(shape[:f32|f64][:generic|:shardRofW]; ne30x72x91 is one rank's block of the 730-snapshot config; "
+                         "(shape[:f32|f64][:generic|:shardRofW]; ne30x72x91 is one rank's block of the 730-snapshot config, "
+                         "ne120x72x4 a time-sharded rank's block of configs[3] -- the no-collective alternative; "
                          ":generic forces the generic sweeps -- what a grid without repeated latitudes gets; :shardRofW is "
-                         "rank R's block of columns of the job ncol-sharded over W ranks, its stages without the all-reduces)")
+                         "rank R's step of the job ncol-sharded over W ranks, its collectives left out)")
     ap.add_argument("--stall-timeout", type=float, default=300.0,
                     help="N > 1: seconds the whole run may take before the watchdog reports a stalled collective")
     args = ap.parse_args()
@@ -220,7 +221,9 @@ def main():
                        symmetry=not args.no_symmetry, classes=not args.no_classes)
     if use_ncol:
         runner = sharding.NcolShardedTEM(plan)
-    plan.set_tem(nlev, nt_l, plev * 100)
+        runner.set_tem(nlev, nt_l, plev * 100)       # (+ the plan-build collectives of the time-sliced tail)
+    else:
+        plan.set_tem(nlev, nt_l, plev * 100)
     torch.cuda.synchronize()
     plan_s = time.perf_counter() - t0
 
@@ -297,9 +300,19 @@ def main():
         "nonfinite": bool(nonfinite),
     }
     if use_ncol:
-        rec["config"]["collectives"] = ("2 all-reduces per step over %s ([4][K][D] and [3][K][D] fp64 = %d bytes) + the "
-                                        "K x K Gram matrix once at plan build"
-                                        % ("RCCL/xGMI" if backend == "nccl" else backend, 7 * K_HARM * nlev * nt * 8))
+        via = "RCCL/xGMI" if backend == "nccl" else backend
+        if runner.sliced:
+            rec["config"]["collectives"] = (
+                "per step over %s: 1 all-reduce of the reference pre-pass sums ([4][16][D] fp64 = %d bytes) + 1 reduce-scatter "
+                "over time of the single sweep's projections ([4 x 101 + 3 x 51][D] fp64 = %d bytes in, 1/%d of it out per "
+                "rank); K x K Gram matrices and the single sweep's two row-sum matrices once at plan build"
+                % (via, 4 * 16 * nlev * nt * 8, (4 * (2 * K_HARM - 1) + 3 * K_HARM) * nlev * nt * 8, world))
+            rec["config"]["tail"] = ("time sliced: every rank finishes its own snapshots (%d..%d of %d on rank 0); the ten "
+                                     "results stay time-sharded" % (runner.my_snapshots()[0], runner.my_snapshots()[1] - 1, nt))
+        else:
+            rec["config"]["collectives"] = ("2 all-reduces per step over %s ([4][K][D] and [3][K][D] fp64 = %d bytes) + the "
+                                            "K x K Gram matrix once at plan build; tail replicated on every rank"
+                                            % (via, 7 * K_HARM * nlev * nt * 8))
     if neddy:
         ach = 7 * 2 * K_HARM * pts_rank / (eddy_ms * 1e-3) / 1e12
         if plan.one_pass and nproj:
@@ -378,30 +391,63 @@ def main():
             try:
                 lat2, lon2 = synth.cubed_sphere_gll(ne2)
                 plev2 = synth.pressure_levels(nlev2)
+                sliced = None
                 if shard:
-                    # one rank's block of the ncol-sharded job (whole latitude classes), finalised with the Gram
-                    # matrix of the whole grid as the all-reduce would leave it; tem_run = the rank's three stages
+                    # One rank's step of the ncol-sharded job, its collectives left out: the job's W plans are built
+                    # over whole latitude classes and given the matrices the plan-build all-reduces leave them with
+                    # (Gram matrices, and for the single sweep Gx and the subsample's Gram matrix); rank R's plan then
+                    # runs exactly what NcolShardedTEM.run makes it run.
                     from pytemdiags_amd import _lib
                     r_s, w_s = (int(x) for x in shard[0][5:].split("of"))
-                    pg = engine.Plan(lat2, lat_zm, K_HARM - 1, device=local_rank)
-                    G2 = pg.matrix(_lib.MAT_GRAM).cpu().numpy()
-                    pg.close()
-                    mine2 = sharding.symmetric_ncol_shards(lat2, w_s)[r_s - 1]
-                    lat2, lon2 = lat2[mine2], lon2[mine2]
-                    p2 = engine.Plan(lat2, lat_zm, K_HARM - 1, device=local_rank, defer_finalize=True)
-                    p2.finalize(G2)
+                    blocks = sharding.symmetric_ncol_shards(lat2, w_s)
+                    pw = [engine.Plan(lat2[m], lat_zm, K_HARM - 1, device=local_rank, defer_finalize=True) for m in blocks]
+                    Gm = sum(q.matrix(_lib.MAT_GRAM) for q in pw).cpu().numpy()
+                    for q in pw:
+                        q.finalize(Gm)
+                    Gm2 = sum(q.matrix(_lib.MAT_GRAM2) for q in pw).cpu().numpy()
+                    for q in pw:
+                        q.refine(Gm2)
+                        q.configure(os_subsample=max(12, -(-96 // w_s)), single_sweep_min_groups=max(64, 2048 // w_s))
+                    p2 = pw[r_s - 1]
+                    p2.set_tem(nlev2, nt2, plev2 * 100)
+                    if p2.single_sweep and nt2 >= w_s:
+                        for q in pw:
+                            if q is not p2:
+                                q.set_tem(nlev2, 1, plev2 * 100)       # (the tables depend on the grid and L only)
+                        Gx = sum(q.matrix(_lib.MAT_GX) for q in pw).cpu().numpy()
+                        Gs = sum(q.matrix(_lib.MAT_GSUB) for q in pw).cpu().numpy()
+                        p2.set_os_matrices(Gx, Gs)
+                        sliced = sharding.shard_bounds(nt2, w_s, r_s - 1)
+                    for q in pw:
+                        if q is not p2:
+                            q.close()
+                    lat2, lon2 = lat2[blocks[r_s - 1]], lon2[blocks[r_s - 1]]
                 else:
                     p2 = engine.Plan(lat2, lat_zm, K_HARM - 1, device=local_rank, symmetry=not generic)
-                p2.set_tem(nlev2, nt2, plev2 * 100)
+                    p2.set_tem(nlev2, nt2, plev2 * 100)
                 same = name == args.workload and dt2_t == tdtype and not shard      # the headline's own fields: reuse them
                 f2 = fields if same else engine.synth_fields(local_rank, lat2, lon2, plev2, nt2, dtype=dt2_t, seed=0)
-                o2 = p2._alloc_results(False)
+                if sliced:
+                    # pre-pass, [all-reduce], sweep + reduction into W time slices, [reduce-scatter], tail on this rank's slice
+                    bA = torch.zeros((4, p2.KR, p2.D), dtype=torch.float64, device=dev)
+                    bP = torch.zeros((w_s, p2.os_rows * nlev2 * -(-nt2 // w_s)), dtype=torch.float64, device=dev)
+                    o2 = torch.empty((10, p2.M, nlev2, sliced[1] - sliced[0]), dtype=torch.float64, device=dev)
+
+                    def step2():
+                        p2.tem_os_prepass(*f2, out=bA)
+                        p2.tem_os_sweep(*f2, bA, nslices=w_s, out=bP)
+                        p2.tem_os_tail(bP[r_s - 1], sliced[0], sliced[1] - sliced[0], out=o2)
+                else:
+                    o2 = p2._alloc_results(False)
+
+                    def step2():
+                        p2.tem_run(*f2, out=o2)
                 for _ in range(3):
-                    p2.tem_run(*f2, out=o2)
+                    step2()
                 torch.cuda.synchronize()
                 reps, t0 = 0, time.perf_counter()
                 while reps < 5 or (time.perf_counter() - t0 < 0.3 and reps < 200):
-                    p2.tem_run(*f2, out=o2)
+                    step2()
                     reps += 1
                     if reps % 10 == 0:
                         torch.cuda.synchronize()
@@ -413,8 +459,12 @@ def main():
                     "plan_symmetry": not generic,
                     "sweeps": ("generic", "mirror-paired", "latitude-class")[p2.sweep_mode]
                               + (", single sweep" if getattr(p2, "single_sweep", False)
-                                 else (", one pass" if p2.one_pass else "")),
+                                 else (", one pass" if p2.one_pass else ""))
+                              + (", time-sliced tail (snapshots %d..%d of %d), collectives left out" % (sliced[0], sliced[1] - 1, nt2)
+                                 if sliced else ""),
                     "frac_of_fp64_roofline": pts2 / dt2 / (PEAK_F64_TFLOPS * 1e12 / FLOPS_PER_PT)}
+                if bool(p2.status()):
+                    rec["other_workloads"][wl]["nonfinite"] = True
                 p2.close()
                 del f2, o2
             except Exception as e:  # noqa: BLE001 - an extra shape must not cost the metric line
@@ -501,7 +551,7 @@ def main():
             p3 = engine.Plan(lat[mine3], lat_zm, K_HARM - 1, device=local_rank, defer_finalize=True,
                              symmetry=not args.no_symmetry, classes=not args.no_classes)
             r3 = sharding.NcolShardedTEM(p3)
-            p3.set_tem(nlev, nt, plev * 100)
+            r3.set_tem(nlev, nt, plev * 100)
             f3 = engine.synth_fields(local_rank, lat[mine3], lon[mine3], plev, nt, t0=0, dtype=tdtype, seed=0)
             e3 = timed(lambda: r3.run(*f3))
             bad3 = p3.status()

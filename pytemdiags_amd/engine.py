@@ -268,15 +268,15 @@ class Plan:
                                         _ptr(zon) if zon is not None else None, self._stream()))
         return res, zon
 
-    def tracer_os_prepass(self, q, va, wap):
+    def tracer_os_prepass(self, q, va, wap, out=None):
         (qq, v, w), dt = self._three(q, va, wap)
-        Asq = torch.empty((self.KR, self.D), dtype=torch.float64, device=self.device)
+        Asq = out if out is not None else torch.empty((self.KR, self.D), dtype=torch.float64, device=self.device)
         check(self.lib.temx_tracer_os_prepass(self._h, _ptr(qq), _ptr(v), _ptr(w), dt, _ptr(Asq), self._stream()))
         return Asq
 
-    def tracer_os_sweep(self, q, va, wap, Asq, nslices=1):
+    def tracer_os_sweep(self, q, va, wap, Asq, nslices=1, out=None):
         (qq, v, w), dt = self._three(q, va, wap)
-        projq = self._sliced(self.KX + 2 * self.K, nslices)
+        projq = out if out is not None else self._sliced(self.KX + 2 * self.K, nslices)
         check(self.lib.temx_tracer_os_sweep(self._h, _ptr(qq), _ptr(v), _ptr(w), dt, _ptr(Asq.contiguous()), int(nslices),
                                             _ptr(projq), self._stream()))
         return projq

@@ -122,7 +122,9 @@ class NcolShardedTEM:
         collectives then run at the first step.)"""
         be = self.backend
         if hasattr(be, "configure") and self.tail != "replicated":
-            be.configure(os_subsample=max(12, -(-96 // self.world)))
+            # the subsample spread over the ranks; and the single sweep chosen by the size of the JOB: with a
+            # time-sliced tail a rank contracts 1 / world of the columns, so the threshold scales with it
+            be.configure(os_subsample=max(12, -(-96 // self.world)), single_sweep_min_groups=max(64, 2048 // self.world))
         be.set_tem(nlev, nt, p_pa, p0)
         self._decide()
 
@@ -155,6 +157,21 @@ class NcolShardedTEM:
     def sliced(self):
         return bool(self._sliced)
 
+    # message buffers of the time-sliced step, kept between steps (allocated zeroed: the padding of a ragged slice is
+    # never written and never read, it only travels)
+    def _buffer(self, name, shape):
+        be = self.backend
+        key = (name, tuple(shape))
+        if key not in self._buf:
+            self._buf[key] = torch.zeros(tuple(shape), dtype=torch.float64, device=getattr(be, "device", torch.device("cpu")))
+        return self._buf[key]
+
+    def _slices(self, name, rows):
+        be = self.backend
+        ntmax = -(-int(be.nt) // self.world)
+        shape = (rows, be.nlev, be.nt) if self.world == 1 else (self.world, rows * be.nlev * ntmax)
+        return self._buffer(name, shape)
+
     def my_snapshots(self):
         """(t0, t1): the snapshots this rank's results describe (the whole run with a replicated tail)."""
         nt = int(self.backend.nt)
@@ -165,10 +182,10 @@ class NcolShardedTEM:
         if self._sliced is None:
             self._decide()
         if self._sliced:
-            As = be.tem_os_prepass(ua, va, ta, wap)
+            As = be.tem_os_prepass(ua, va, ta, wap, out=self._buffer("As", (4, be.KR, be.D)))
             allreduce_sum_(As, self.group)             # (ii) reference pre-pass sums [4][KR][D], one message
-            proj = be.tem_os_sweep(ua, va, ta, wap, As, nslices=self.world)
-            mine = reduce_scatter_sum(proj, self.group)    # (iii) projections, one time slice per rank
+            proj = be.tem_os_sweep(ua, va, ta, wap, As, nslices=self.world, out=self._slices("proj", be.os_rows))
+            mine = reduce_scatter_sum(proj, self.group, out=self._buffer("mine", proj.shape[1:]))    # (iii) projections, one time slice per rank
             t0, t1 = shard_bounds(int(be.nt), self.world, self.rank)
             return be.tem_os_tail(mine, t0, t1 - t0, want_zonal)
         B4 = be.tem_stage1(ua, va, ta, wap)
@@ -187,10 +204,10 @@ class NcolShardedTEM:
         [2][K][D] sums of q'v', q'w')."""
         be = self.backend
         if self._sliced:
-            Asq = be.tracer_os_prepass(q, va, wap)
+            Asq = be.tracer_os_prepass(q, va, wap, out=self._buffer("Asq", (be.KR, be.D)))
             allreduce_sum_(Asq, self.group)
-            projq = be.tracer_os_sweep(q, va, wap, Asq, nslices=self.world)
-            mine = reduce_scatter_sum(projq, self.group)
+            projq = be.tracer_os_sweep(q, va, wap, Asq, nslices=self.world, out=self._slices("projq", be.KX + 2 * be.K))
+            mine = reduce_scatter_sum(projq, self.group, out=self._buffer("mineq", projq.shape[1:]))
             t0, t1 = shard_bounds(int(be.nt), self.world, self.rank)
             return be.tracer_os_tail(mine, t1 - t0, want_zonal)
         if getattr(be, "tracer_one_pass", False):      # (q, v, omega) read once, see include/temx.h

@@ -139,8 +139,13 @@ def test_config3_full_size_eight_ncol_shards_equal_the_unsharded_run():
     plans = [engine.Plan(lat[p], _zm_lat(), 50, defer_finalize=True) for p in parts]
     G = sum(pl.matrix(_lib.MAT_GRAM) for pl in plans).cpu().numpy()              # all-reduce (i)
     B4 = None
-    for pl, p in zip(plans, parts):
+    for pl in plans:
         pl.finalize(G)
+    G2 = sum(pl.matrix(_lib.MAT_GRAM2) for pl in plans).cpu().numpy()            # all-reduce (i')
+    for pl, p in zip(plans, parts):
+        pl.refine(G2)
+        # as NcolShardedTEM.set_tem: the reference subsample spread over the ranks, the form chosen by the size of the job
+        pl.configure(os_subsample=12, single_sweep_min_groups=2048 // W)
         pl.set_tem(72, nt, plev * 100)
         idx = torch.as_tensor(p, device="cuda:0")
         loc = [x[idx] for x in f]
@@ -164,6 +169,35 @@ def test_config3_full_size_eight_ncol_shards_equal_the_unsharded_run():
             den = float(ref[i].abs().max())
             assert float((res[i] - ref[i]).abs().max()) <= 1e-11 * den, n
     assert not any(pl.status() for pl in plans)
+    # ---- round 4: what NcolShardedTEM runs on these plans by default -- the single sweep with a time-sliced tail.
+    # Plan-build all-reduces of the two row-sum matrices, per step one all-reduce (pre-pass sums) and one
+    # reduce-scatter over time (projections); rank w finishes the snapshots shard_bounds(30, 8, w) = 4, 4, 4, 4, 4, 4, 3, 3.
+    if all(pl.single_sweep for pl in plans):
+        Gx = sum(pl.matrix(_lib.MAT_GX) for pl in plans).cpu().numpy()
+        Gs = sum(pl.matrix(_lib.MAT_GSUB) for pl in plans).cpu().numpy()
+        As = None
+        for pl, p in zip(plans, parts):
+            pl.set_os_matrices(Gx, Gs)
+            idx = torch.as_tensor(p, device="cuda:0")
+            a = pl.tem_os_prepass(*[x[idx] for x in f])
+            As = a if As is None else As + a                                        # all-reduce
+        proj = None
+        for pl, p in zip(plans, parts):
+            idx = torch.as_tensor(p, device="cuda:0")
+            b = pl.tem_os_sweep(*[x[idx] for x in f], As, nslices=W)
+            proj = b if proj is None else proj + b                                  # reduce-scatter: rank w keeps proj[w]
+        outs = []
+        for w, pl in enumerate(plans):
+            t0, t1 = sharding.shard_bounds(nt, W, w)
+            outs.append(pl.tem_os_tail(proj[w], t0, t1 - t0)[0])
+        got = torch.cat(outs, dim=-1)
+        assert got.shape == ref.shape
+        for i, n in enumerate(_lib.RESULT_NAMES):
+            den = float(ref[i].abs().max())
+            assert float((got[i] - ref[i]).abs().max()) <= 1e-11 * den, n
+        assert not any(pl.status() for pl in plans)
+    else:
+        assert any(os.environ.get(k) in ("0", "1") for k in ("TEMX_NO_SYM", "TEMX_NO_CLS", "TEMX_TWO_PASS", "TEMX_SINGLE_SWEEP", "TEMX_NO_QR"))
     for pl in plans:
         pl.close()
     del f

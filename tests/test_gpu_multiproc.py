@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NE, NLEV, NT = 8, 12, 5
+NE, NLEV, NT = 8, 12, 5          # D = 60: four d-tiles, the smallest shape the one-pass forms take
 
 
 def _inputs():
@@ -38,14 +38,25 @@ def _worker(rank, world, port, mode, ret):
     try:
         lat, plev, f, q, lat_zm = _inputs()
         dev = lambda x: torch.as_tensor(np.ascontiguousarray(x), device="cuda:0")   # noqa: E731
-        if mode == "ncol":
+        if mode in ("ncol", "ncol-sliced"):
             mine = sharding.symmetric_ncol_shards(lat, world)[rank]
-            plan = engine.Plan(lat[mine], lat_zm, 50, defer_finalize=True)
-            runner = sharding.NcolShardedTEM(plan)
-            plan.set_tem(NLEV, NT, plev * 100)
+            # "ncol-sliced": the plans run the single sweep (forced: this grid is below the automatic threshold), the
+            # tail is time sliced -- all-reduce of the pre-pass sums, reduce-scatter of the projections, this rank
+            # finishes its own snapshots; the assembled time axis must be the unsharded run
+            plan = engine.Plan(lat[mine], lat_zm, 50, defer_finalize=True,
+                               form="single-sweep" if mode == "ncol-sliced" else None)
+            runner = sharding.NcolShardedTEM(plan, tail="sliced" if mode == "ncol-sliced" else "replicated")
+            if mode == "ncol-sliced":
+                runner.set_tem(NLEV, NT, plev * 100)
+                assert runner.sliced and runner.my_snapshots() == sharding.shard_bounds(NT, world, rank)
+            else:
+                plan.set_tem(NLEV, NT, plev * 100)
             loc = [dev(x[mine]) for x in f]
             res, _ = runner.run(*loc)
             tres, _ = runner.run_tracer(dev(q[mine]), loc[1], loc[3])
+            if mode == "ncol-sliced":
+                assert res.shape[-1] == runner.my_snapshots()[1] - runner.my_snapshots()[0]
+                res, tres = sharding.gather_time(res), sharding.gather_time(tres)
             out = torch.cat([res, tres])
             paired = plan.paired
         else:
@@ -72,7 +83,7 @@ def _port():
     return p
 
 
-@pytest.mark.parametrize("mode", ["ncol", "time"])
+@pytest.mark.parametrize("mode", ["ncol", "ncol-sliced", "time"])
 def test_two_ranks_on_one_gpu(mode):
     import torch.multiprocessing as mp
     from pytemdiags_amd import engine
@@ -100,7 +111,7 @@ def test_two_ranks_on_one_gpu(mode):
     d = [torch.as_tensor(x, device="cuda:0") for x in f]
     ref, _ = plan.tem_run(*d)
     ref = ref.cpu().numpy()
-    if mode == "ncol":
+    if mode.startswith("ncol"):
         tref, _ = plan.tracer_run(torch.as_tensor(q, device="cuda:0"), d[1], d[3])
         ref = np.concatenate([ref, tref.cpu().numpy()])
     plan.close()

@@ -117,6 +117,135 @@ class OnePassOracleBackend(OracleBackend):
         return OracleBackend.tracer_stage2(self, *self._kept_q, Bq)
 
 
+class SingleSweepOracleBackend(OracleBackend):
+    """Stand-in with the three-step interface of the single sweep (engine.Plan.tem_os_prepass / _sweep / _tail and
+    the tracer's three; include/temx.h): the sweep hands over projections of the fields (minus a low-degree
+    reference fitted to a subsample) up to degree 2L and of their products up to degree L, written as time slices;
+    the tail gets the eddy-product sums of ITS snapshots from them by the Legendre product linearisation on
+    Gauss-Legendre nodes -- the algebra of os_contract_kernel in numpy, which is what makes a time-sliced tail
+    possible: nothing in it needs a second look at the rows."""
+    single_sweep = True
+    device = torch.device("cpu")
+
+    def __init__(self, lat_local, lat_out, L, plev, nt):
+        super().__init__(lat_local, lat_out, L, plev)
+        self.L, self.K, self.KX, self.KR = L, L + 1, 2 * L + 1, min(16, L + 1)
+        self.nlev, self.nt, self.D = len(plev), nt, len(plev) * nt
+        self.os_rows = 4 * self.KX + 3 * self.K
+        self.Yx = orc.ylm0_matrix_recurrence(lat_local, 2 * L)
+        self.sub = np.arange(0, lat_local.size, 3)                    # this rank's share of the reference subsample
+        xg, wg = np.polynomial.legendre.leggauss(2 * L + 2)
+        self.Yg = orc.ylm0_matrix_recurrence(np.rad2deg(np.arcsin(xg)), 2 * L)
+        self.wg = 2 * np.pi * wg
+        self.Gx = self.Gs = None
+
+    def matrix(self, which):
+        if which == sharding.MAT_GX:
+            return torch.from_numpy(self.Y0.T @ self.Yx)
+        if which == sharding.MAT_GSUB:
+            Ys = self.Y0[self.sub][:, :self.KR]
+            return torch.from_numpy(Ys.T @ Ys)
+        return super().matrix(which)
+
+    def finalize(self, G):
+        self.G = np.array(G)
+        super().finalize(G)
+
+    def configure(self, **kw):
+        pass
+
+    def set_tem(self, nlev, nt, p_pa, p0=None):
+        assert (nlev, nt) == (self.nlev, self.nt)
+
+    def set_os_matrices(self, Gx, Gs):
+        self.Gx, self.Gs = np.array(Gx), np.array(Gs)
+
+    def _slices(self, rows2d, W):      # [rows][D] -> [W][rows * nlev * ntmax], slice w packed as [rows][nlev][ntw]
+        a = rows2d.reshape(rows2d.shape[0], self.nlev, self.nt)
+        ntmax = -(-self.nt // W)
+        out = np.zeros((W, rows2d.shape[0] * self.nlev * ntmax))
+        for w in range(W):
+            t0, t1 = sharding.shard_bounds(self.nt, W, w)
+            out[w, : a.shape[0] * self.nlev * (t1 - t0)] = a[:, :, t0:t1].reshape(-1)
+        return torch.from_numpy(out if W > 1 else a.copy())
+
+    def _prepass(self, X):
+        Ys = self.Y0[self.sub][:, :self.KR]
+        return np.stack([Ys.T @ x[self.sub] for x in X])
+
+    def tem_os_prepass(self, ua, va, ta, wap, out=None):
+        return torch.from_numpy(self._prepass(self._f(ua, va, ta, wap)[0]))
+
+    def _sweep(self, X, As, pairs):
+        assert self.Gs is not None, "set_os_matrices (the all-reduced matrices) must precede the sweep"
+        rho = [np.linalg.solve(self.Gs, a) for a in np.asarray(As)]            # [KR][D] per field
+        Xs = [x - self.Y0[:, :self.KR] @ r for x, r in zip(X, rho)]            # shifted fields: same eddies
+        return rho, Xs, [self.Y0.T @ (Xs[a] * Xs[b]) for a, b in pairs]
+
+    def tem_os_sweep(self, ua, va, ta, wap, As, nslices=1, out=None):
+        X, _ = self._f(ua, va, ta, wap)
+        self.rho, Xs, P = self._sweep(X, As.numpy().reshape(4, self.KR, self.D), [(0, 1), (0, 3), (1, 2)])
+        self._kept_vw = (Xs[1], Xs[3])
+        return self._slices(np.concatenate([self.Yx.T @ x for x in Xs] + P), nslices)
+
+    def _lin(self, A, al, B, be, P):
+        """sum_i Y_l (a - abar)(b - bbar) from A, B (degree-2L projections), the coefficients of the zonal means and P"""
+        At, Bt = self.Yg @ A, self.Yg @ B                                      # synthesis at the nodes
+        ab, bb = self.Yg[:, :self.K] @ al, self.Yg[:, :self.K] @ be
+        cross = self.Yg[:, :self.K].T @ (self.wg[:, None] * (bb * At + ab * Bt))
+        c = self.Yg.T @ (self.wg[:, None] * (ab * bb))
+        return P - cross + self.Gx @ c
+
+    def _cols(self, t0, nts):          # columns (lev, t0 + t) of the whole run
+        return (np.arange(self.nlev)[:, None] * self.nt + t0 + np.arange(nts)[None, :]).reshape(-1)
+
+    def tem_os_tail(self, mine, t0, nts, want_zonal=False):
+        m = mine.numpy().reshape(-1)[: self.os_rows * self.nlev * nts].reshape(self.os_rows, self.nlev * nts)
+        A = [m[f * self.KX:(f + 1) * self.KX] for f in range(4)]
+        P = [m[4 * self.KX + k * self.K: 4 * self.KX + (k + 1) * self.K] for k in range(3)]
+        al = [self.Ginv @ a[:self.K] for a in A]
+        cols = self._cols(t0, nts)
+        tr = (self.nlev, nts)
+        # zonal means of the ORIGINAL fields: the reference comes back exactly
+        C = [a + np.pad(r[:, cols], ((0, self.K - self.KR), (0, 0))) for a, r in zip(al, self.rho)]
+        self.zon = {n: (self.Y0p @ c).reshape((-1,) + tr) for n, c in zip(("ub", "vb", "thetab", "wapb"), C)}
+        for n, (a, b), p in zip(("upvpb", "upwappb", "vptpb"), [(0, 1), (0, 3), (1, 2)], P):
+            F = self._lin(A[a], al[a], A[b], al[b], p)
+            self.zon[n] = (self.Y0p @ (self.Ginv @ F)).reshape((-1,) + tr)
+        self._tail = (t0, nts, A, al)
+        o = orc.TEMOracle.from_zonal_means(self.zon, self.plev)
+        return torch.from_numpy(np.stack([getattr(o, n)() for n in orc.RESULTS])), None
+
+    def tracer_os_prepass(self, q, va, wap, out=None):
+        qf = np.asarray(q).reshape(q.shape[0], -1)
+        return torch.from_numpy(self._prepass([qf])[0])
+
+    def tracer_os_sweep(self, q, va, wap, Asq, nslices=1, out=None):
+        qf = np.asarray(q).reshape(q.shape[0], -1)
+        self.rho_q = np.linalg.solve(self.Gs, Asq.numpy())
+        qs = qf - self.Y0[:, :self.KR] @ self.rho_q
+        vs, ws = self._kept_vw                                                # (the same v, omega as the TEM run)
+        return self._slices(np.concatenate([self.Yx.T @ qs, self.Y0.T @ (qs * vs), self.Y0.T @ (qs * ws)]), nslices)
+
+    def tracer_os_tail(self, mine, nts, want_zonal=False):
+        t0, nts0, A, al = self._tail
+        assert nts == nts0
+        rows = self.KX + 2 * self.K
+        m = mine.numpy().reshape(-1)[: rows * self.nlev * nts].reshape(rows, self.nlev * nts)
+        Aq, P = m[:self.KX], [m[self.KX + k * self.K: self.KX + (k + 1) * self.K] for k in range(2)]
+        alq = self.Ginv @ Aq[:self.K]
+        tr = (self.nlev, nts)
+        cq = alq + np.pad(self.rho_q[:, self._cols(t0, nts)], ((0, self.K - self.KR), (0, 0)))
+        zq = {"qb": (self.Y0p @ cq).reshape((-1,) + tr)}
+        for n, f, p in zip(("qpvpb", "qpwappb"), (1, 3), P):
+            zq[n] = (self.Y0p @ (self.Ginv @ self._lin(Aq, alq, A[f], al[f], p))).reshape((-1,) + tr)
+        o = orc.TEMOracle.from_zonal_means(self.zon, self.plev)
+        o.q = [np.empty(0)]
+        o.qb, o.qpvpb, o.qpwappb = [zq["qb"]], [zq["qpvpb"]], [zq["qpwappb"]]
+        o._derivatives()
+        return torch.from_numpy(np.stack([getattr(o, n)(0) for n in orc.TRACER_RESULTS])), None
+
+
 _LON = synth.cubed_sphere_gll(NE)[1]
 
 
@@ -134,13 +263,23 @@ def _worker(rank, world, port, mode, ret):
     try:
         lat, plev, f = _data()
         lat_zm = orc.zm_latitudes(1)
-        if mode in ("ncol", "ncol-one-pass"):
+        if mode in ("ncol", "ncol-one-pass", "ncol-sliced"):
             i0, i1 = sharding.shard_bounds(lat.size, world, rank)
-            be = (OracleBackend if mode == "ncol" else OnePassOracleBackend)(lat[i0:i1], lat_zm, L, plev)
-            runner = sharding.NcolShardedTEM(be)
+            if mode == "ncol-sliced":
+                be = SingleSweepOracleBackend(lat[i0:i1], lat_zm, L, plev, NT)
+                runner = sharding.NcolShardedTEM(be, tail="sliced")
+                runner.set_tem(NLEV, NT, plev * 100)
+                assert runner.sliced
+            else:
+                be = (OracleBackend if mode == "ncol" else OnePassOracleBackend)(lat[i0:i1], lat_zm, L, plev)
+                runner = sharding.NcolShardedTEM(be)
             res, _ = runner.run(*[x[i0:i1] for x in f])
             q = synth.analytic_tracer(lat, _LON, plev, NT)
             tres, _ = runner.run_tracer(q[i0:i1], f[1][i0:i1], f[3][i0:i1])
+            if mode == "ncol-sliced":      # every rank holds its own snapshots: ragged 3 + 2 of NT = 5
+                t0, t1 = runner.my_snapshots()
+                assert (t0, t1) == sharding.shard_bounds(NT, world, rank) and res.shape[-1] == t1 - t0
+                res, tres = sharding.gather_time(res), sharding.gather_time(tres)
             res = torch.cat([res, tres])
         else:
             be = OracleBackend(lat, lat_zm, L, plev)
@@ -163,7 +302,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("mode", ["ncol", "ncol-one-pass", "time"])
+@pytest.mark.parametrize("mode", ["ncol", "ncol-one-pass", "ncol-sliced", "time"])
 def test_sharded_pipeline_world2_gloo(mode):
     lat, plev, f = _data()
     q = synth.analytic_tracer(lat, _LON, plev, NT)
