@@ -407,13 +407,14 @@ def main():
                     Gm2 = sum(q.matrix(_lib.MAT_GRAM2) for q in pw).cpu().numpy()
                     for q in pw:
                         q.refine(Gm2)
-                        q.configure(os_subsample=max(12, -(-96 // w_s)), single_sweep_min_groups=max(64, 2048 // w_s))
+                        q.configure(os_subsample=max(8, -(-32 // w_s)), single_sweep_min_groups=max(64, 640 // w_s))
                     p2 = pw[r_s - 1]
                     p2.set_tem(nlev2, nt2, plev2 * 100)
                     if p2.single_sweep and nt2 >= w_s:
                         for q in pw:
                             if q is not p2:
-                                q.set_tem(nlev2, 1, plev2 * 100)       # (the tables depend on the grid and L only)
+                                q.configure(form="single-sweep")       # (the tables depend on the grid and L only: a small
+                                q.set_tem(nlev2, 1, plev2 * 100)       #  shape builds them, forced past the size threshold)
                         Gx = sum(q.matrix(_lib.MAT_GX) for q in pw).cpu().numpy()
                         Gs = sum(q.matrix(_lib.MAT_GSUB) for q in pw).cpu().numpy()
                         p2.set_os_matrices(Gx, Gs)
@@ -423,7 +424,9 @@ def main():
                             q.close()
                     lat2, lon2 = lat2[blocks[r_s - 1]], lon2[blocks[r_s - 1]]
                 else:
-                    p2 = engine.Plan(lat2, lat_zm, K_HARM - 1, device=local_rank, symmetry=not generic)
+                    forms = [x for x in parts[2:] if x in ("single-sweep", "class-sums", "two-pass")]
+                    p2 = engine.Plan(lat2, lat_zm, K_HARM - 1, device=local_rank, symmetry=not generic,
+                                     form=forms[0] if forms else None)
                     p2.set_tem(nlev2, nt2, plev2 * 100)
                 same = name == args.workload and dt2_t == tdtype and not shard      # the headline's own fields: reuse them
                 f2 = fields if same else engine.synth_fields(local_rank, lat2, lon2, plev2, nt2, dtype=dt2_t, seed=0)

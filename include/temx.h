@@ -61,12 +61,14 @@ enum {
                                       4 rows x 16 columns (env: TEMX_OS_MAP=tile) */
   TEMX_OPT_OP_MAP = 3,             /* the same for sweep 1 of the class-sum form (env: TEMX_OP_MAP=tile) */
   TEMX_OPT_OS_SUBSAMPLE = 4,       /* class-groups of this plan's rows that enter the reference fit of the single
-                                      sweep (default 96; an ncol-sharded job wants about 96 / ranks per rank; set
+                                      sweep (default 32; an ncol-sharded job wants about 32 / ranks per rank, at least 8; set
                                       before temx_plan_set_tem builds the tables; env: TEMX_OS_SUBSAMPLE) */
   TEMX_OPT_TRACER_ONE_PASS = 5,    /* temx_tracer_run on the class-sum form: 1 = one-pass tracer stages
                                       (env: TEMX_TRACER_ONE_PASS=1) */
-  TEMX_OPT_SINGLE_SWEEP_MIN_GROUPS = 6 /* smallest number of class-groups for which the automatic choice takes the
-                                      single sweep (default 2048) */
+  TEMX_OPT_SINGLE_SWEEP_MIN_GROUPS = 6, /* smallest number of class-groups for which the automatic choice takes the
+                                      single sweep (default 640) */
+  TEMX_OPT_OS_CONTRACT = 7         /* single sweep, the contraction after it: 0 on the matrix cores (default), 1 the
+                                      round-3 form with the matrices staged in LDS (A/B; env: TEMX_OS_CONTRACT=lds) */
 };
 enum {
   TEMX_FORM_AUTO = -1,
@@ -185,7 +187,7 @@ int temx_plan_sweep_mode(const temx_plan* plan);
  * 8 x 512 B per class-group and d-tile; TEMX_TWO_PASS=1 in the environment disables, TEMX_ONE_PASS=1
  * lifts the size threshold. */
 int temx_plan_one_pass(const temx_plan* plan);
-/* 1 when temx_tem_run takes the SINGLE-SWEEP form (one-pass class path on a grid with >= 2048 class-groups,
+/* 1 when temx_tem_run takes the SINGLE-SWEEP form (one-pass class path on a grid with >= 640 class-groups,
  * L <= 51; TEMX_SINGLE_SWEEP=0 / =1 in the environment disables / forces where possible): no per-class sums
  * are stored at all.  One sweep projects the four fields -- minus a band-limited reference of degree <= 15
  * fitted to a subsample of the latitude classes in a short pre-pass -- up to degree 2L, and their three

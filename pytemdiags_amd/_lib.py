@@ -19,7 +19,7 @@ NO_CLASSES = 4
 NO_QR = 8
 MAT_Y0, MAT_Y0P, MAT_GRAM, MAT_GINV, MAT_Y0INV, MAT_GRAM2, MAT_GX, MAT_GSUB = 0, 1, 2, 3, 4, 5, 6, 7
 # temx_plan_configure options and the forms of the latitude-class sweeps (include/temx.h)
-OPT_FORM, OPT_OS_MAP, OPT_OP_MAP, OPT_OS_SUBSAMPLE, OPT_TRACER_ONE_PASS, OPT_SINGLE_SWEEP_MIN_GROUPS = 1, 2, 3, 4, 5, 6
+OPT_FORM, OPT_OS_MAP, OPT_OP_MAP, OPT_OS_SUBSAMPLE, OPT_TRACER_ONE_PASS, OPT_SINGLE_SWEEP_MIN_GROUPS, OPT_OS_CONTRACT = 1, 2, 3, 4, 5, 6, 7
 FORM_AUTO, FORM_TWO_PASS, FORM_CLASS_SUMS, FORM_SINGLE_SWEEP, FORM_NO_SINGLE_SWEEP = -1, 0, 1, 2, 3
 FORMS = {"auto": FORM_AUTO, "two-pass": FORM_TWO_PASS, "class-sums": FORM_CLASS_SUMS,
          "single-sweep": FORM_SINGLE_SWEEP, "no-single-sweep": FORM_NO_SINGLE_SWEEP}

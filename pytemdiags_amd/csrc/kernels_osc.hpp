@@ -1,0 +1,213 @@
+// kernels_osc.hpp -- the contraction of the single sweep on the matrix cores (round 4; replaces os_contract_kernel
+// of kernels_op2.hpp, which stays for A/B: TEMX_OPT_OS_CONTRACT / TEMX_OS_CONTRACT=lds).
+//
+// From the projections of the single sweep to the raw sums the rest of the pipeline takes (the algebra is stated at
+// os_contract_kernel; tem_diagnostics.py:547-557 are the products it replaces).  Every step is a small fixed matrix
+// applied to columns, so it runs as 4x4x4 fp64 MFMAs on [4 x 16] tiles of 16 columns: one wave = one d-tile of one
+// field (or of one pair of fields), a tile of a product comes out in the B-operand layout of the next product.  Two
+// kernels instead of one, because the pair step needs the synthesis of two fields:
+//
+//   osc_fields_kernel  per (field, d-tile):  alpha = T (G2inv (T^T A[:K])),  B4 = T^T (A[:K] + G[:, :KR] rho),
+//                      At = Yq A,  ab = Yq[:, :K] alpha            -> At, ab [field][NQ rows][Dt]  (and B4)
+//   osc_pairs_kernel   per (pair, d-tile):   U = w (ab_b At_a + ab_a At_b),  V = w ab_a ab_b  (per node, VALU),
+//                      cross = Yq[:, :K]^T U,  c = Yq^T V,  F = P - cross + Gx c,  B3 = T^T F
+//
+// The first version of this contraction (os_contract_kernel) stages every matrix in LDS and walks them with scalar
+// FMAs, 4 columns per workgroup: 0.23 ms at D = 2160 and growing with D beyond one round of workgroups -- the reason
+// the single sweep stopped at grids with >= 2048 class-groups.  A one-kernel MFMA form was measured in round 3 at
+// 0.20 ms (59 dependent phases of one L2 latency each on 135 workgroups).  Here the vectors of a d-tile live in
+// wave-private LDS in the operand layout, the matrix blocks stream from L2 through a register ring PF steps ahead of
+// the MFMAs that use them (the loops are rolled: written unrolled, the compiler hoisted every block load of a product
+// and spilled), and a workgroup is one wave, so the ~950 waves of the two launches spread over the chip.
+//
+// Matrices are 4x4 A-operand blocks built on the host (append_blocks): blk[(mb * NKB + kb) * 16 + k * 4 + i] =
+// M[4 mb + i][4 kb + k], zero padded to whole blocks; a lane's element of a block is at g * 4 + (lane & 3), g = lane >> 4.
+#pragma once
+#include "kernels_op2.hpp"
+
+namespace temx {
+
+struct OscMats {
+  const double* Tt;      // [NBK][NBK]  T^T
+  const double* G2inv;   // [NBK][NBK]
+  const double* T;       // [NBK][NBK]
+  const double* Gk;      // [NBK][4]    G[:, :KR]  (Gram matrix of Y0, Y basis)
+  const double* YqK;     // [NBX][NBK]  Yq[:, :K]
+  const double* Yq;      // [NBX][NBX]  Yq[q][k], k < KX
+  const double* YqKt;    // [NBK][NBX]  Yq[:, :K]^T
+  const double* Yqt;     // [NBX][NBX]  Yq^T
+  const double* Gx;      // [NBK][NBX]
+};
+
+#ifndef TEMX_OSC_PF
+#define TEMX_OSC_PF 4
+#endif
+constexpr int OSC_PF = TEMX_OSC_PF;       // matrix blocks are loaded this many steps ahead of their MFMAs
+
+// MC output blocks mb0 .. mb0 + MC - 1 of  M . x:  acc[mb] = init(mb) + sum_kb blk[mb][kb] . x[kb],  kb < KI.
+// x: the operand tiles in LDS, xl[kb * 64] is this lane's element of tile kb.  The loop over kb is rolled (PF steps
+// per trip, the remainder peeled), the MC accumulators are independent MFMA chains.  Every step issues its block
+// loads unconditionally (past the end: block KI - 1 again, never used): a conditional issue makes the compiler's
+// wait counts conservative, and the first version of this loop waited for all loads in flight at every step.
+template <int MC, int KI, typename Init, typename Out>
+__device__ __forceinline__ void osc_mm(const double* __restrict__ blk, int mb0, const double* xl, uint32_t aoff,
+                                       Init init, Out out) {
+  constexpr int PF = OSC_PF < KI ? OSC_PF : KI;
+  double acc[MC], ring[PF][MC];
+  const double* __restrict__ b = blk + (size_t)mb0 * KI * 16 + aoff;
+#pragma unroll
+  for (int mb = 0; mb < MC; ++mb) acc[mb] = init(mb0 + mb);
+  static_for<PF - 1>([&](auto pc) __attribute__((always_inline)) {
+    constexpr int p = decltype(pc)::value;
+#pragma unroll
+    for (int mb = 0; mb < MC; ++mb) ring[p][mb] = b[(mb * KI + p) * 16];
+  });
+  auto step = [&](auto jc, int k) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value;
+    const int kn = k + PF - 1 < KI ? k + PF - 1 : KI - 1;
+#pragma unroll
+    for (int mb = 0; mb < MC; ++mb) ring[(j + PF - 1) % PF][mb] = b[(mb * KI + kn) * 16];
+    const double x = xl[k * 64];
+#pragma unroll
+    for (int mb = 0; mb < MC; ++mb) acc[mb] = TEMX_MFMA4(ring[j][mb], x, acc[mb]);
+  };
+  constexpr int TRIPS = KI / PF, REM = KI % PF;
+#pragma unroll 1
+  for (int t = 0; t < TRIPS; ++t)
+    static_for<PF>([&](auto jc) __attribute__((always_inline)) { step(jc, t * PF + decltype(jc)::value); });
+  static_for<REM>([&](auto jc) __attribute__((always_inline)) { step(jc, TRIPS * PF + decltype(jc)::value); });
+#pragma unroll
+  for (int mb = 0; mb < MC; ++mb) out(mb0 + mb, acc[mb]);
+}
+
+// nf fields: A[f] [KX][Dt] (projections of the shifted field), rho[f] [KR][Drho] (only for f < nout)
+struct OscFieldsIn {
+  const double* A[4];
+  const double* rho[4];
+};
+
+// LDS doubles per workgroup (= wave)
+__host__ __device__ constexpr int osc_fields_lds(int NBK) { return (2 * NBK + 2 * NBK + 4) * 64; }
+__host__ __device__ constexpr int osc_pairs_lds(int NBK) { return (3 * 2 * NBK + 2 * NBK) * 64; }
+
+template <int NBK>
+__global__ void __launch_bounds__(64)
+osc_fields_kernel(OscFieldsIn in, OscMats m, int K, int KX, int KR, int NQ, int64_t Dt, int nout,
+                  double* __restrict__ B4 /* [nout][K][Dt] */, double* __restrict__ At /* [nf][NQ][Dt] */,
+                  double* __restrict__ ab /* [nf][NQ][Dt] */, int64_t Drho, int nts, int nt, int t0) {
+  constexpr int NBX = 2 * NBK;
+  extern __shared__ double sm[];             // [NBX] a | [NBK] t0 | [NBK] t1 | [4] rho   tiles of 64 lanes
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x;
+  const int g = lane >> 4, c = lane & 15;
+  const int64_t d = (int64_t)blockIdx.x * 16 + c;
+  const bool dvalid = d < Dt;
+  const int64_t dcl = dvalid ? d : Dt - 1;
+  const uint32_t aoff = (uint32_t)(g * 4 + (lane & 3));
+  double* va = sm + lane;
+  double* vt0 = va + NBX * 64;
+  double* vt1 = vt0 + NBK * 64;
+  double* vr = vt1 + NBK * 64;
+  const double* __restrict__ Af = in.A[f];
+#pragma unroll
+  for (int kb = 0; kb < NBX; ++kb) {
+    const int row = 4 * kb + g;
+    const double v = Af[(int64_t)(row < KX ? row : KX - 1) * Dt + dcl];
+    va[kb * 64] = row < KX ? v : 0.0;
+  }
+  auto zero = [](int) { return 0.0; };
+  // (rows >= K of A ride along in the last block of A[:K]: the matrices are zero there)
+  // ---- coefficients of the zonal mean of the shifted field: alpha = T (G2inv (T^T A[:K]))  -> vt0
+  osc_mm<NBK, NBK>(m.Tt, 0, va, aoff, zero, [&](int mb, double v) { vt0[mb * 64] = v; });
+  osc_mm<NBK, NBK>(m.G2inv, 0, vt0, aoff, zero, [&](int mb, double v) { vt1[mb * 64] = v; });
+  osc_mm<NBK, NBK>(m.T, 0, vt1, aoff, zero, [&](int mb, double v) { vt0[mb * 64] = v; });
+  // ---- raw sums of the ORIGINAL field in the plan's basis: B4 = T^T (A[:K] + G[:, :KR] rho)
+  if (f < nout) {
+    // the references are those of the whole run ([KR][Drho]); this call may work on the snapshots [t0, t0 + nts)
+    const int64_t lev = dcl / nts, dg = lev * nt + t0 + (dcl - lev * nts);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const int row = 4 * kb + g;
+      const double v = in.rho[f][(int64_t)(row < KR ? row : KR - 1) * Drho + dg];
+      vr[kb * 64] = row < KR ? v : 0.0;
+    }
+    osc_mm<NBK, 4>(m.Gk, 0, vr, aoff, [&](int mb) { return va[mb * 64]; }, [&](int mb, double v) { vt1[mb * 64] = v; });
+    osc_mm<NBK, NBK>(m.Tt, 0, vt1, aoff, zero, [&](int mb, double v) {
+      if (dvalid && 4 * mb + g < K) B4[((int64_t)f * K + 4 * mb + g) * Dt + d] = v;
+    });
+  }
+  // ---- synthesis at the Gauss-Legendre nodes: ab = Yq[:, :K] alpha, At = Yq A   (NBX output blocks: two halves)
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    osc_mm<NBK, NBK>(m.YqK, h * NBK, vt0, aoff, zero, [&](int mb, double v) {
+      if (dvalid && 4 * mb + g < NQ) ab[((int64_t)f * NQ + 4 * mb + g) * Dt + d] = v;
+    });
+    osc_mm<NBK, NBX>(m.Yq, h * NBK, va, aoff, zero, [&](int mb, double v) {
+      if (dvalid && 4 * mb + g < NQ) At[((int64_t)f * NQ + 4 * mb + g) * Dt + d] = v;
+    });
+  }
+}
+
+// per pair p: the synthesised fields a = pa(p), b = pb(p) ([NQ][Dt] each) and the projection of their product [K][Dt]
+struct OscPairsIn {
+  const double* At_a[3];
+  const double* At_b[3];
+  const double* ab_a[3];
+  const double* ab_b[3];
+  const double* P[3];
+};
+
+template <int NBK>
+__global__ void __launch_bounds__(64)
+osc_pairs_kernel(OscPairsIn in, OscMats m, const double* __restrict__ wq2, int K, int KX, int NQ, int64_t Dt,
+                 double* __restrict__ B3 /* [np][K][Dt] */) {
+  constexpr int NBX = 2 * NBK;
+  extern __shared__ double sm[];             // [NBX] U | [NBX] V | [NBX] c | [NBK] cross | [NBK] F
+  const int p = blockIdx.y;
+  const int lane = threadIdx.x;
+  const int g = lane >> 4, c = lane & 15;
+  const int64_t d = (int64_t)blockIdx.x * 16 + c;
+  const bool dvalid = d < Dt;
+  const int64_t dcl = dvalid ? d : Dt - 1;
+  const uint32_t aoff = (uint32_t)(g * 4 + (lane & 3));
+  double* vU = sm + lane;
+  double* vV = vU + NBX * 64;
+  double* vc = vV + NBX * 64;
+  double* vx = vc + NBX * 64;
+  double* vF = vx + NBK * 64;
+  const double* __restrict__ Ata = in.At_a[p];
+  const double* __restrict__ Atb = in.At_b[p];
+  const double* __restrict__ aba = in.ab_a[p];
+  const double* __restrict__ abb = in.ab_b[p];
+  // ---- products at the nodes:  U_q = w_q (bb At_a + aa At_b),  V_q = w_q aa bb
+#pragma unroll
+  for (int kb = 0; kb < NBX; ++kb) {
+    const int q = 4 * kb + g;
+    const int qc = q < NQ ? q : NQ - 1;
+    const double w = q < NQ ? wq2[qc] : 0.0;
+    const int64_t o = (int64_t)qc * Dt + dcl;
+    const double ta = Ata[o], tb = Atb[o], aa = aba[o], bb = abb[o];
+    vU[kb * 64] = w * (bb * ta + aa * tb);
+    vV[kb * 64] = w * (aa * bb);
+  }
+  auto zero = [](int) { return 0.0; };
+  // ---- projected back:  cross_l = sum_q Y_l(x_q) U_q,   c_k = sum_q Y_k(x_q) V_q
+  osc_mm<NBK, NBX>(m.YqKt, 0, vU, aoff, zero, [&](int mb, double v) { vx[mb * 64] = v; });
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h)
+    osc_mm<NBK, NBX>(m.Yqt, h * NBK, vV, aoff, zero, [&](int mb, double v) { vc[mb * 64] = v; });
+  // ---- F = P - cross + Gx c,  B3 = T^T F
+  const double* __restrict__ Pp = in.P[p];
+  osc_mm<NBK, NBX>(m.Gx, 0, vc, aoff,
+              [&](int mb) {
+                const int row = 4 * mb + g;
+                const double v = Pp[(int64_t)(row < K ? row : K - 1) * Dt + dcl];
+                return (row < K ? v : 0.0) - vx[mb * 64];
+              },
+              [&](int mb, double v) { vF[mb * 64] = v; });
+  osc_mm<NBK, NBK>(m.Tt, 0, vF, aoff, zero, [&](int mb, double v) {
+    if (dvalid && 4 * mb + g < K) B3[((int64_t)p * K + 4 * mb + g) * Dt + d] = v;
+  });
+}
+
+}  // namespace temx

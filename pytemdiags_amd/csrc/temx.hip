@@ -21,6 +21,7 @@
 #include "kernels_cls.hpp"
 #include "kernels_op.hpp"
 #include "kernels_op2.hpp"
+#include "kernels_osc.hpp"
 #include "side_tables.hpp"
 
 using namespace temx;
@@ -142,7 +143,14 @@ struct temx_plan {
   int64_t sgroups = 0, sbatches = 0;
   DevBuf ycx, ycx_s, crow_s, rho, rho0, gaunt /* Yq[NQ][KX] */, wq2, Gx, Gsinv, Ax /* [4 KX + 3 K][D]: projections of the fields, then of the products */, Axs /* [4][KR][D] */;
   std::vector<double> h_Gx, h_Gs;      // this plan's rows: Y0^T Y0ext [K][KX] and the subsample's Gram matrix [KR][KR] (all-reduced when ncol-sharded)
-  int os_keep = 96;                    // class-groups of the reference subsample (TEMX_OPT_OS_SUBSAMPLE)
+  // contraction of the single sweep on the matrix cores (kernels_osc.hpp): host copies of its matrices, their 4x4
+  // blocks on the device (one buffer), the synthesised fields At / ab [4][NQ][D] (kept: the tracer pairs with v, omega)
+  std::vector<double> h_T, h_Ginv, h_G, h_Yq;
+  DevBuf oscblk, osAt, osAb, osAtq, osAbq;
+  OscMats osc{};
+  bool osc_lds = false;                // TEMX_OPT_OS_CONTRACT = 1 / TEMX_OS_CONTRACT=lds: the round-3 LDS form (A/B)
+  int opt_os_contract = -1;
+  int os_keep = 32;                    // class-groups of the reference subsample (TEMX_OPT_OS_SUBSAMPLE): 128 latitudes for 16 coefficients per column
   // what the tail of the pipeline (solve, contraction, scan, epilogue) currently describes: the snapshots
   // [tt0, tt0 + tnt) of the run, tD = nlev * tnt columns.  The whole run unless a time-sliced tail ran last.
   int64_t tD = 0, tnt = 0, tt0 = 0;
@@ -299,8 +307,13 @@ static int upload_blocks(DevBuf& dst, const double* A, int R, int K, int TB) {
   return upload(dst, blk.data(), blk.size() * 8);
 }
 
+static int os_upload_blocks(temx_plan* pl);
+
 static int set_ginv(temx_plan* pl, const double* Gi_host) {
   HIPCHK(hipMemcpy(pl->Ginv.p, Gi_host, (size_t)pl->K * pl->K * 8, hipMemcpyHostToDevice));
+  pl->h_Ginv.assign(Gi_host, Gi_host + (size_t)pl->K * pl->K);
+  if (pl->os_built)
+    if (int rc = os_upload_blocks(pl)) return rc;
   if (pl->K > 64) return TEMX_OK;
   // Ginv padded to 4*TB rows: upload_blocks wants TB row-blocks
   std::vector<double> Gp((size_t)4 * pl->TB * pl->K, 0.0);
@@ -1463,7 +1476,9 @@ static int build_os_tables(temx_plan* pl) {
       hipLaunchKernelGGL(cls_basis_kernel<512>, dim3((unsigned)((pl->cls_npad + 255) / 256)), dim3(256), 0, 0, pl->xc.d(),
                          pl->ncls, pl->cls_npad, KX, TBX, nd.d(), (const double*)nullptr, pl->ycx.d());
       // subsample of class-groups for the reference fit: every S-th group, its batches copied
-      // (about 100 class-groups = 400 latitudes for the 16 coefficients of a column; env TEMX_OS_SUBSAMPLE: groups kept)
+      // (32 class-groups = 128 latitudes for the 16 coefficients of a column -- the fit only has to be decent, it is
+      // removed again exactly; 96 groups cost 0.15 instead of 0.06 ms at ne120 x 72 x 30 and 0.5 instead of 0.2 ms at
+      // ne30 x 72 x 91.  TEMX_OPT_OS_SUBSAMPLE / env TEMX_OS_SUBSAMPLE: groups kept)
       const char* ess = getenv("TEMX_OS_SUBSAMPLE");
       const int64_t keep = ess ? std::max(4, atoi(ess)) : pl->os_keep;
       const int64_t S = std::max<int64_t>(1, std::min<int64_t>(256, pl->cgroups / keep));
@@ -1556,6 +1571,7 @@ static int build_os_tables(temx_plan* pl) {
       w2[(size_t)q] = (double)(twopi * wq[(size_t)q]);
     }
     if ((rc = upload(pl->gaunt, Yq.data(), Yq.size() * 8))) return rc;       // (Yq[q][k])
+    pl->h_Yq = Yq;
     if ((rc = upload(pl->wq2, w2.data(), w2.size() * 8))) return rc;
   }
   // Gx[l][k] = sum over the native columns of Y_l Y_k, l < K, k < KX (per latitude class; host threads)
@@ -1600,6 +1616,47 @@ static int build_os_tables(temx_plan* pl) {
     pl->h_Gx = std::move(Gx);
   }
   pl->os_built = true;
+  return os_upload_blocks(pl);
+}
+
+// 4x4 A-operand blocks (kernels_osc.hpp) of the R x C matrix A (row-major, leading dimension ld), zero padded to
+// nrb x nkb blocks, appended to `out`
+static void append_blocks(std::vector<double>& out, const double* A, int R, int C, int ld, bool transpose, int nrb, int nkb) {
+  const size_t o = out.size();
+  out.resize(o + (size_t)nrb * nkb * 16, 0.0);
+  for (int rb = 0; rb < nrb; ++rb)
+    for (int t = 0; t < nkb; ++t)
+      for (int k = 0; k < 4; ++k)
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * rb + i, c = 4 * t + k;          // element [r][c] of the (transposed) matrix
+          if (r < R && c < C) out[o + ((size_t)rb * nkb + t) * 16 + k * 4 + i] = transpose ? A[(size_t)c * ld + r] : A[(size_t)r * ld + c];
+        }
+}
+
+// the matrices of the single sweep's contraction as MFMA operand blocks: after build_os_tables, and again whenever
+// one of them changes (temx_plan_finalize / refine: T, G2inv, G; temx_plan_set_os_matrices: Gx)
+static int os_upload_blocks(temx_plan* pl) {
+  if (pl->h_T.empty() || pl->h_Ginv.empty() || pl->h_G.empty() || pl->h_Yq.empty() || pl->h_Gx.empty()) return TEMX_OK;
+  const int K = pl->K, KX = pl->KX, KR = pl->KR, NQ = pl->NQ;
+  const int NBK = pl->TB, NBX = 2 * pl->TBX;
+  if (4 * NBK < K || 4 * NBX < KX || 4 * NBX < NQ) return fail(TEMX_EUNSUPPORTED, "single-sweep contraction: no instantiation for L = %d", pl->L);
+  std::vector<double> blk;
+  size_t off[9];
+  const double* T = pl->h_T.data();
+  const double* Yq = pl->h_Yq.data();
+  off[0] = blk.size(); append_blocks(blk, T, K, K, K, true, NBK, NBK);                    // T^T
+  off[1] = blk.size(); append_blocks(blk, pl->h_Ginv.data(), K, K, K, false, NBK, NBK);   // G2inv
+  off[2] = blk.size(); append_blocks(blk, T, K, K, K, false, NBK, NBK);                   // T
+  off[3] = blk.size(); append_blocks(blk, pl->h_G.data(), K, KR, K, false, NBK, 4);       // G[:, :KR]
+  off[4] = blk.size(); append_blocks(blk, Yq, NQ, K, KX, false, NBX, NBK);                // Yq[:, :K]
+  off[5] = blk.size(); append_blocks(blk, Yq, NQ, KX, KX, false, NBX, NBX);               // Yq
+  off[6] = blk.size(); append_blocks(blk, Yq, K, NQ, KX, true, NBK, NBX);                 // Yq[:, :K]^T
+  off[7] = blk.size(); append_blocks(blk, Yq, KX, NQ, KX, true, NBX, NBX);                // Yq^T
+  off[8] = blk.size(); append_blocks(blk, pl->h_Gx.data(), K, KX, KX, false, NBK, NBX);   // Gx
+  HIPCHK(hipDeviceSynchronize());              // (a launch in flight may still read the old blocks)
+  if (int rc = upload(pl->oscblk, blk.data(), blk.size() * 8)) return rc;
+  const double* b = pl->oscblk.d();
+  pl->osc = OscMats{b + off[0], b + off[1], b + off[2], b + off[3], b + off[4], b + off[5], b + off[6], b + off[7], b + off[8]};
   return TEMX_OK;
 }
 
@@ -1707,6 +1764,27 @@ static SliceMap slice_map(const temx_plan* pl, int nsl, int64_t rows_total, int6
   return m;
 }
 
+// the contraction on the matrix cores (kernels_osc.hpp): fields, then pairs
+template <int NBK>
+static int launch_osc_t(temx_plan* pl, const OscFieldsIn& fin, int nf, int nout, double* Bf, double* At, double* ab,
+                        const OscPairsIn& pin, int np, double* Bp, int64_t Dt, hipStream_t st) {
+  const unsigned gx = (unsigned)((Dt + 15) / 16);       // one wave = one workgroup = one d-tile of one field / pair
+  hipLaunchKernelGGL((osc_fields_kernel<NBK>), dim3(gx, nf), dim3(64), (size_t)osc_fields_lds(NBK) * 8, st, fin, pl->osc, pl->K,
+                     pl->KX, pl->KR, pl->NQ, Dt, nout, Bf, At, ab, pl->D, (int)pl->tnt, (int)pl->nt, (int)pl->tt0);
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL((osc_pairs_kernel<NBK>), dim3(gx, np), dim3(64), (size_t)osc_pairs_lds(NBK) * 8, st, pin, pl->osc, pl->wq2.d(),
+                     pl->K, pl->KX, pl->NQ, Dt, Bp);
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+static int launch_osc(temx_plan* pl, const OscFieldsIn& fin, int nf, int nout, double* Bf, double* At, double* ab,
+                      const OscPairsIn& pin, int np, double* Bp, int64_t Dt, hipStream_t st) {
+  if (pl->TB == 13 && pl->TBX == 13) return launch_osc_t<13>(pl, fin, nf, nout, Bf, At, ab, pin, np, Bp, Dt, st);
+  if (pl->TB == 8 && pl->TBX == 8) return launch_osc_t<8>(pl, fin, nf, nout, Bf, At, ab, pin, np, Bp, Dt, st);
+  if (pl->TB == 4 && pl->TBX == 4) return launch_osc_t<4>(pl, fin, nf, nout, Bf, At, ab, pin, np, Bp, Dt, st);
+  return fail(TEMX_EUNSUPPORTED, "single-sweep contraction: no instantiation for L = %d", pl->L);
+}
+
 // ---- the single sweep in three steps.  A single process runs them back to back (tem_run_os); an ncol-sharded job
 // exchanges between them: (1) -> all-reduce of As (4 x KR x D doubles) -> (2) -> reduce-scatter of proj over time
 // -> (3) on the snapshots the rank received.
@@ -1761,15 +1839,33 @@ static int os_tail(temx_plan* pl, const double* proj_s, int64_t t0, int64_t nts,
     const size_t lds = os_contract_lds(pl->K, pl->KX, pl->NQ) * 8;
     static std::atomic<uint64_t> attr_set{0};
     if ((rc = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(os_contract_kernel<0>), 160 * 1024))) return rc;
-    OsFields in;
-    for (int f = 0; f < 4; ++f) {
-      in.A[f] = pl->Ax.d() + (int64_t)f * pl->KX * Dt;
-      in.rho[f] = pl->rho.d() + (int64_t)f * pl->KR * pl->D;
+    const double* Pp = pl->Ax.d() + (int64_t)4 * pl->KX * Dt;
+    if (pl->osc_lds) {
+      OsFields in;
+      for (int f = 0; f < 4; ++f) {
+        in.A[f] = pl->Ax.d() + (int64_t)f * pl->KX * Dt;
+        in.rho[f] = pl->rho.d() + (int64_t)f * pl->KR * pl->D;
+      }
+      hipLaunchKernelGGL(os_contract_kernel<0>, dim3((unsigned)((Dt + OSC - 1) / OSC)), dim3(256), lds, st, in, Pp, pl->K, pl->KX,
+                         pl->KR, pl->NQ, Dt, pl->T.d(), pl->Ginv.d(), pl->G.d(), pl->Gx.d(), pl->gaunt.d(), pl->wq2.d(),
+                         pl->B4.d(), pl->B3.d(), pl->D, (int)nts, (int)pl->nt, (int)t0);
+      HIPCHK(hipGetLastError());
+    } else {
+      using KD = OsKind<0>;
+      const int64_t QD = (int64_t)pl->NQ * Dt;
+      OscFieldsIn fin;
+      OscPairsIn pin{};
+      for (int f = 0; f < 4; ++f) {
+        fin.A[f] = pl->Ax.d() + (int64_t)f * pl->KX * Dt;
+        fin.rho[f] = pl->rho.d() + (int64_t)f * pl->KR * pl->D;
+      }
+      for (int k = 0; k < 3; ++k) {
+        pin.At_a[k] = pl->osAt.d() + KD::pa(k) * QD; pin.At_b[k] = pl->osAt.d() + KD::pb(k) * QD;
+        pin.ab_a[k] = pl->osAb.d() + KD::pa(k) * QD; pin.ab_b[k] = pl->osAb.d() + KD::pb(k) * QD;
+        pin.P[k] = Pp + (int64_t)k * pl->K * Dt;
+      }
+      if ((rc = launch_osc(pl, fin, 4, 4, pl->B4.d(), pl->osAt.d(), pl->osAb.d(), pin, 3, pl->B3.d(), Dt, st))) return rc;
     }
-    hipLaunchKernelGGL(os_contract_kernel<0>, dim3((unsigned)((Dt + OSC - 1) / OSC)), dim3(256), lds, st, in,
-                       pl->Ax.d() + (int64_t)4 * pl->KX * Dt, pl->K, pl->KX, pl->KR, pl->NQ, Dt, pl->T.d(), pl->Ginv.d(), pl->G.d(),
-                       pl->Gx.d(), pl->gaunt.d(), pl->wq2.d(), pl->B4.d(), pl->B3.d(), pl->D, (int)nts, (int)pl->nt, (int)t0);
-    HIPCHK(hipGetLastError());
     time_end(pl, 1, st, t2);
   }
   // as after stage 2: coefficients and zonal means of the four fields, then the epilogue
@@ -1799,6 +1895,8 @@ static int tracer_os_ws(temx_plan* pl) {
   int rc;
   if ((rc = tracer_ws(pl))) return rc;
   if ((rc = pl->Axq.ensure((size_t)(pl->KX + 2 * pl->K + pl->KR) * D * 8))) return rc;   // projections, then the pre-pass sums
+  if ((rc = pl->osAtq.ensure((size_t)pl->NQ * D * 8))) return rc;
+  if ((rc = pl->osAbq.ensure((size_t)pl->NQ * D * 8))) return rc;
   return pl->rho_t.ensure((size_t)3 * pl->KR * D * 8);
 }
 
@@ -1841,17 +1939,33 @@ static int tracer_os_tail(temx_plan* pl, const double* projq_s, double* tres, do
     const size_t lds = os_contract_lds(pl->K, pl->KX, pl->NQ) * 8;
     static std::atomic<uint64_t> attr_set{0};
     if ((rc = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(os_contract_kernel<1>), 160 * 1024))) return rc;
-    OsFields in{};
-    in.A[0] = projq_s;
-    in.A[1] = pl->Ax.d() + 1 * KXD;
-    in.A[2] = pl->Ax.d() + 3 * KXD;
-    in.rho[0] = pl->rho_t.d();
-    in.rho[1] = pl->rho.d() + 1 * KRD;
-    in.rho[2] = pl->rho.d() + 3 * KRD;
-    hipLaunchKernelGGL(os_contract_kernel<1>, dim3((unsigned)((Dt + OSC - 1) / OSC)), dim3(256), lds, st, in, projq_s + KXD,
-                       pl->K, pl->KX, pl->KR, pl->NQ, Dt, pl->T.d(), pl->Ginv.d(), pl->G.d(), pl->Gx.d(), pl->gaunt.d(),
-                       pl->wq2.d(), pl->Bq.d(), pl->Bq2.d(), pl->D, (int)pl->tnt, (int)pl->nt, (int)pl->tt0);
-    HIPCHK(hipGetLastError());
+    if (pl->osc_lds) {
+      OsFields in{};
+      in.A[0] = projq_s;
+      in.A[1] = pl->Ax.d() + 1 * KXD;
+      in.A[2] = pl->Ax.d() + 3 * KXD;
+      in.rho[0] = pl->rho_t.d();
+      in.rho[1] = pl->rho.d() + 1 * KRD;
+      in.rho[2] = pl->rho.d() + 3 * KRD;
+      hipLaunchKernelGGL(os_contract_kernel<1>, dim3((unsigned)((Dt + OSC - 1) / OSC)), dim3(256), lds, st, in, projq_s + KXD,
+                         pl->K, pl->KX, pl->KR, pl->NQ, Dt, pl->T.d(), pl->Ginv.d(), pl->G.d(), pl->Gx.d(), pl->gaunt.d(),
+                         pl->wq2.d(), pl->Bq.d(), pl->Bq2.d(), pl->D, (int)pl->tnt, (int)pl->nt, (int)pl->tt0);
+      HIPCHK(hipGetLastError());
+    } else {
+      // q is synthesised here; v and omega at the nodes are those the TEM tail left in the plan (osAt / osAb)
+      const int64_t QD = (int64_t)pl->NQ * Dt;
+      OscFieldsIn fin{};
+      OscPairsIn pin{};
+      fin.A[0] = projq_s;
+      fin.rho[0] = pl->rho_t.d();
+      const int other[2] = {1, 3};                   // v, omega among the TEM run's four fields
+      for (int k = 0; k < 2; ++k) {
+        pin.At_a[k] = pl->osAtq.d(); pin.ab_a[k] = pl->osAbq.d();
+        pin.At_b[k] = pl->osAt.d() + other[k] * QD; pin.ab_b[k] = pl->osAb.d() + other[k] * QD;
+        pin.P[k] = projq_s + KXD + (int64_t)k * pl->K * Dt;
+      }
+      if ((rc = launch_osc(pl, fin, 1, 1, pl->Bq.d(), pl->osAtq.d(), pl->osAbq.d(), pin, 2, pl->Bq2.d(), Dt, st))) return rc;
+    }
   }
   // coefficients Ct = (C_q, C_v, C_w) and qb -> tz[0], as the other tracer stage 2 forms leave them
   const size_t slab = (size_t)pl->K4 * Dt * 8;
@@ -1909,7 +2023,7 @@ void temx_plan_destroy(temx_plan* pl) {
   pl->ypblk.release();
   for (DevBuf* b : {&pl->T, &pl->Qp, &pl->GinvA, &pl->G2, &pl->xo, &pl->xc, &pl->ycx, &pl->ycx_s, &pl->crow_s, &pl->side_crow[0][0], &pl->side_crow[0][1], &pl->side_crow[1][0], &pl->side_crow[1][1],
                     &pl->side_gfirst[0][0], &pl->side_gfirst[0][1], &pl->side_gfirst[1][0], &pl->side_gfirst[1][1], &pl->rho,
-                    &pl->rho0, &pl->gaunt, &pl->wq2, &pl->Axq, &pl->rho_t, &pl->Gx, &pl->Gsinv, &pl->Ax, &pl->Axs})
+                    &pl->rho0, &pl->gaunt, &pl->wq2, &pl->Axq, &pl->rho_t, &pl->Gx, &pl->Gsinv, &pl->Ax, &pl->Axs, &pl->oscblk, &pl->osAt, &pl->osAb, &pl->osAtq, &pl->osAbq})
     b->release();
   for (auto& kv : pl->csplits_s) kv.second.release();
   for (auto& kv : pl->csplits) kv.second.release();
@@ -2201,6 +2315,7 @@ int temx_plan_finalize(temx_plan* pl, const double* G_host) {
   }
   for (double v : G)
     if (!std::isfinite(v)) return fail(TEMX_EINVAL, "Gram matrix is not finite (NaN latitudes?)");
+  pl->h_G = G;                    // (as on the device: before the odd entries are cleared)
   if (pl->qbasis) {               // finalised before: back to the Y0 basis the Gram matrix refers to
     if (int rcb = build_all_bases(pl, nullptr)) return rcb;
     pl->qbasis = false;
@@ -2247,6 +2362,7 @@ int temx_plan_finalize(temx_plan* pl, const double* G_host) {
       for (int j = l; j < K; ++j) T[(size_t)l * K + j] = (double)Li[(size_t)j * K + l];   // R^-1 = (L^-1)^T
     }
     if (int rct = upload(pl->T, T.data(), T.size() * 8)) return rct;
+    pl->h_T = T;
     if (int rcb = build_all_bases(pl, pl->T.d())) return rcb;
     pl->qbasis = true;
     if (int rcg = set_ginv(pl, I.data())) return rcg;      // until temx_plan_refine
@@ -2395,6 +2511,8 @@ int temx_plan_set_os_matrices(temx_plan* pl, const double* Gx_host, const double
   HIPCHK(hipDeviceSynchronize());
   if (int rc = upload(pl->Gsinv, Gi.data(), Gi.size() * 8)) return rc;
   if (int rc = upload(pl->Gx, Gx_host, (size_t)pl->K * pl->KX * 8)) return rc;
+  pl->h_Gx.assign(Gx_host, Gx_host + (size_t)pl->K * pl->KX);
+  if (int rc = os_upload_blocks(pl)) return rc;
   pl->os_need_global = false;
   pl->os_valid = false;
   return TEMX_OK;
@@ -2488,6 +2606,7 @@ int temx_plan_configure(temx_plan* pl, int option, int value) {
       pl->os_keep = value;
       break;
     case TEMX_OPT_SINGLE_SWEEP_MIN_GROUPS: pl->opt_single_sweep_min_groups = value; break;
+    case TEMX_OPT_OS_CONTRACT: pl->opt_os_contract = value; break;
     default: return fail(TEMX_EINVAL, "unknown option %d", option);
   }
   pl->tem = false;                // the choice is made in temx_plan_set_tem: call it (again)
@@ -2503,6 +2622,7 @@ int temx_plan_option(const temx_plan* pl, int option) {
     case TEMX_OPT_TRACER_ONE_PASS: return tracer_one_pass_wanted(pl) ? 1 : 0;
     case TEMX_OPT_OS_SUBSAMPLE: return pl->os_keep;
     case TEMX_OPT_SINGLE_SWEEP_MIN_GROUPS: return pl->opt_single_sweep_min_groups;
+    case TEMX_OPT_OS_CONTRACT: return pl->osc_lds ? 1 : 0;
     default: return -1;
   }
 }
@@ -2523,6 +2643,10 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
   pl->onepass = pl->lone = pl->op_valid = pl->xb_valid = pl->tq_valid = false;
   pl->os_on = pl->os_valid = false;
   pl->os_tile = tile_map(pl->opt_os_map, "TEMX_OS_MAP");
+  {
+    const char* e = getenv("TEMX_OS_CONTRACT");
+    pl->osc_lds = e ? !strcmp(e, "lds") : pl->opt_os_contract == 1;
+  }
   pl->op_tile = tile_map(pl->opt_op_map, "TEMX_OP_MAP");
   pl->nlev = nlev;
   pl->nt = nt;
@@ -2647,7 +2771,11 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
           // class-sum form, =1 also takes it on small grids
           {
             const bool off = fc.os == 0, forced = fc.os == 1;
-            const int64_t min_groups = pl->opt_single_sweep_min_groups >= 0 ? pl->opt_single_sweep_min_groups : 2048;
+            // Both forms cost in proportion to D; the class-sum form also in proportion to the rows (its store stream and
+            // the flux kernel), the single sweep pays a pre-pass and a contraction that do not depend on them.  Measured
+            // break-even near 600 class-groups (ne30, 760 groups: 2.49 against 2.80 ms at 72 x 91, 0.86 against 0.96 at
+            // 72 x 30; round 3, with the contraction in LDS and 96 groups in the pre-pass: 2048).
+            const int64_t min_groups = pl->opt_single_sweep_min_groups >= 0 ? pl->opt_single_sweep_min_groups : 640;
             bool want = !off && os_supported(pl) && (forced || pl->cgroups >= min_groups);
             if (want) {
               rc = build_os_tables(pl);
@@ -2662,6 +2790,8 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
               if ((rc = pl->partial.ensure(std::max((size_t)std::max(pl->sp_os.nsplit, pl->sp_os_s.nsplit) * per, pl->partial.bytes)))) return rc;
               if ((rc = pl->Ax.ensure(((size_t)4 * pl->KX + 3 * pl->K) * D * 8))) return rc;
               if ((rc = pl->Axs.ensure((size_t)4 * pl->KR * D * 8))) return rc;
+              if ((rc = pl->osAt.ensure((size_t)4 * pl->NQ * D * 8))) return rc;
+              if ((rc = pl->osAb.ensure((size_t)4 * pl->NQ * D * 8))) return rc;
               if ((rc = pl->rho.ensure((size_t)4 * pl->KR * D * 8))) return rc;
               if ((rc = pl->rho0.ensure((size_t)4 * pl->KR * D * 8))) return rc;
               HIPCHK(hipMemset(pl->rho0.p, 0, pl->rho0.bytes));

@@ -75,7 +75,7 @@ class Plan:
         return self.one_pass and self.option(_lib.OPT_TRACER_ONE_PASS) == 1
 
     def configure(self, form=None, os_map=None, op_map=None, os_subsample=None, tracer_one_pass=None,
-                  single_sweep_min_groups=None):
+                  single_sweep_min_groups=None, os_contract=None):
         """Path selection (temx_plan_configure); ``set_tem`` must follow.  ``form``: a key of ``_lib.FORMS``
         ("auto", "two-pass", "class-sums", "single-sweep", "no-single-sweep"); ``os_map`` / ``op_map``:
         "row" or "tile" (lane map of the loads of the single sweep / of sweep 1 of the class-sum form)."""
@@ -92,6 +92,8 @@ class Plan:
             put(_lib.OPT_TRACER_ONE_PASS, 1 if tracer_one_pass else 0)
         if single_sweep_min_groups is not None:
             put(_lib.OPT_SINGLE_SWEEP_MIN_GROUPS, single_sweep_min_groups)
+        if os_contract is not None:     # "mfma" (default) or "lds" (the round-3 form, A/B)
+            put(_lib.OPT_OS_CONTRACT, {"mfma": 0, "lds": 1}[os_contract] if isinstance(os_contract, str) else os_contract)
         self.nlev = self.nt = self.D = None
 
     def option(self, opt):

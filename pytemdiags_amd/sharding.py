@@ -124,7 +124,7 @@ class NcolShardedTEM:
         if hasattr(be, "configure") and self.tail != "replicated":
             # the subsample spread over the ranks; and the single sweep chosen by the size of the JOB: with a
             # time-sliced tail a rank contracts 1 / world of the columns, so the threshold scales with it
-            be.configure(os_subsample=max(12, -(-96 // self.world)), single_sweep_min_groups=max(64, 2048 // self.world))
+            be.configure(os_subsample=max(8, -(-32 // self.world)), single_sweep_min_groups=max(64, 640 // self.world))
         be.set_tem(nlev, nt, p_pa, p0)
         self._decide()
 

@@ -145,7 +145,7 @@ def test_config3_full_size_eight_ncol_shards_equal_the_unsharded_run():
     for pl, p in zip(plans, parts):
         pl.refine(G2)
         # as NcolShardedTEM.set_tem: the reference subsample spread over the ranks, the form chosen by the size of the job
-        pl.configure(os_subsample=12, single_sweep_min_groups=2048 // W)
+        pl.configure(os_subsample=8, single_sweep_min_groups=640 // W)
         pl.set_tem(72, nt, plev * 100)
         idx = torch.as_tensor(p, device="cuda:0")
         loc = [x[idx] for x in f]

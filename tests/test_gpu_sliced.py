@@ -207,3 +207,32 @@ def test_configure_selects_the_forms():
         assert _relerr(rt[i], res["single-sweep"][i]) <= 1e-11, n
     for p in plans.values():
         p.close()
+
+
+@pytest.mark.parametrize("ne,nlev,nt,dtype,L", [(12, 10, 7, np.float64, 50), (10, 9, 8, np.float64, 28), (10, 16, 5, np.float64, 12),
+                                                (12, 16, 5, np.float32, 40)])
+def test_contraction_on_the_matrix_cores_equals_the_lds_form(ne, nlev, nt, dtype, L):
+    """The contraction after the single sweep (kernels_osc.hpp: two MFMA kernels) against its round-3 form
+    (os_contract_kernel, matrices staged in LDS, TEMX_OPT_OS_CONTRACT = 1): the same algebra, TEM and tracer."""
+    from pytemdiags_amd import _lib, engine
+    _skip_if_forced_elsewhere()
+    if os.environ.get("TEMX_OS_CONTRACT"):
+        pytest.skip("TEMX_OS_CONTRACT overrides the option")
+    lat, lon, plev, f, q, lat_zm = _case(ne, nlev, nt, dtype)
+    d = [_dev(x) for x in f]
+    dq = _dev(q)
+    out = {}
+    for form in ("mfma", "lds"):
+        plan = engine.Plan(lat, lat_zm, L, form="single-sweep")
+        plan.configure(os_contract=form)
+        plan.set_tem(nlev, nt, plev * 100)
+        assert plan.single_sweep and plan.option(_lib.OPT_OS_CONTRACT) == (1 if form == "lds" else 0)
+        r, z = plan.tem_run(*d, want_zonal=True)
+        t, _ = plan.tracer_run(dq, d[1], d[3])
+        assert not plan.status()
+        out[form] = (r, z, t)
+        plan.close()
+    tol = 1e-12 if dtype == np.float64 else 1e-6
+    for a, b, names in zip(out["mfma"], out["lds"], (_lib.RESULT_NAMES, _lib.ZONAL_NAMES, _lib.TRACER_RESULT_NAMES)):
+        for i, n in enumerate(names):
+            assert _relerr(a[i], b[i]) <= tol, n
