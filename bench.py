@@ -146,6 +146,9 @@ def main():
                          "ne120x72x4 a time-sharded rank's block of configs[3] -- the no-collective alternative; "
                          ":generic forces the generic sweeps -- what a grid without repeated latitudes gets; :shardRofW is "
                          "rank R's step of the job ncol-sharded over W ranks, its collectives left out)")
+    ap.add_argument("--exact-mirror", action="store_true",
+                    help="build the southern hemisphere of the synthetic grid as the bit-for-bit mirror of the northern one "
+                         "(rounds 1-3); default: latitudes as the construction leaves them, equal within a class to round-off")
     ap.add_argument("--stall-timeout", type=float, default=300.0,
                     help="N > 1: seconds the whole run may take before the watchdog reports a stalled collective")
     args = ap.parse_args()
@@ -179,7 +182,7 @@ def main():
     from pytemdiags_amd import engine, sharding, synth
 
     ne, nlev, nt = parse_workload(args.workload)
-    lat, lon = synth.cubed_sphere_gll(ne)
+    lat, lon = synth.cubed_sphere_gll(ne, mirror=args.exact_mirror)
     plev = synth.pressure_levels(nlev)
     lat_zm = zm_lat(1.0)
     tdtype = torch.float64 if args.dtype == "f64" else torch.float32
@@ -389,7 +392,7 @@ def main():
             dt2_t = {"": tdtype, "f64": torch.float64, "f32": torch.float32}[dt_s]
             ne2, nlev2, nt2 = parse_workload(name)
             try:
-                lat2, lon2 = synth.cubed_sphere_gll(ne2)
+                lat2, lon2 = synth.cubed_sphere_gll(ne2, mirror=args.exact_mirror)
                 plev2 = synth.pressure_levels(nlev2)
                 sliced = None
                 if shard:
@@ -526,7 +529,7 @@ def main():
             # BASELINE configs[2]: one job of nt_all snapshots, each rank its own contiguous block (ragged
             # blocks: 91/92 at N = 8), replicated plan, no collective on the data path; strong scaling
             ne2, nlev2, nt_all = parse_workload(args.time_workload)
-            lat2, lon2 = synth.cubed_sphere_gll(ne2)
+            lat2, lon2 = synth.cubed_sphere_gll(ne2, mirror=args.exact_mirror)
             plev2 = synth.pressure_levels(nlev2)
             ta, tb = sharding.shard_bounds(nt_all, world, rank)
             p2 = engine.Plan(lat2, lat_zm, K_HARM - 1, device=local_rank, symmetry=not args.no_symmetry,

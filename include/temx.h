@@ -48,8 +48,11 @@ enum {
   TEMX_DEFER_FINALIZE = 1,
   TEMX_NO_SYMMETRY = 2,  /* generic sweeps only: neither latitude classes nor mirror pairing */
   TEMX_NO_CLASSES = 4,   /* do not use the latitude-class sweeps (mirror pairing is still tried) */
-  TEMX_NO_QR = 8         /* keep the Y0 basis and the explicit inverse of the normal equations (A/B runs; see
+  TEMX_NO_QR = 8,        /* keep the Y0 basis and the explicit inverse of the normal equations (A/B runs; see
                             temx_plan_finalize).  TEMX_NO_QR=0/1 in the environment overrides */
+  TEMX_LAT_TOL_F32 = 16  /* the fields will be fp32 (results compared to ~1e-5): latitudes are matched to 1e-8 degrees
+                            instead of 1e-11 when latitude classes / mirror pairs are looked for, so that grids
+                            whose latitude coordinate carries more noise keep the class sweeps (error ~ L x tol) */
 };
 
 /* Path selection (temx_plan_configure; takes effect at the next temx_plan_set_tem, which must follow).  The
@@ -134,7 +137,8 @@ int temx_device_count(void);
  *                   TEMX_NO_CLASSES / TEMX_NO_CLS=1 disables.
  *   mirror-paired   every column has a mirror column at the opposite latitude: 54 % of the matrix work.
  *   generic         any grid.  TEMX_NO_SYMMETRY / TEMX_NO_SYM=1 forces it.
- * Latitudes are matched to within 1e-12 degrees (TEMX_SYM_TOL_DEG in the environment widens that). */
+ * Latitudes are matched to within 1e-11 degrees (1e-8 with TEMX_LAT_TOL_F32; TEMX_SYM_TOL_DEG in the environment
+ * sets the tolerance outright). */
 int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
                      const double* lat_deg_host, const double* lat_out_deg_host, int flags);
 

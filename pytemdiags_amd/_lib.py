@@ -17,6 +17,7 @@ DEFER_FINALIZE = 1
 NO_SYMMETRY = 2
 NO_CLASSES = 4
 NO_QR = 8
+LAT_TOL_F32 = 16
 MAT_Y0, MAT_Y0P, MAT_GRAM, MAT_GINV, MAT_Y0INV, MAT_GRAM2, MAT_GX, MAT_GSUB = 0, 1, 2, 3, 4, 5, 6, 7
 # temx_plan_configure options and the forms of the latitude-class sweeps (include/temx.h)
 OPT_FORM, OPT_OS_MAP, OPT_OP_MAP, OPT_OS_SUBSAMPLE, OPT_TRACER_ONE_PASS, OPT_SINGLE_SWEEP_MIN_GROUPS, OPT_OS_CONTRACT = 1, 2, 3, 4, 5, 6, 7

@@ -573,18 +573,18 @@ static int project_all(temx_plan* pl, const FieldPtrs<NF>& fp, int dtype, int64_
 // ------------------------------------------------------------------------------------------------
 // mirror pairing of an equatorially symmetric grid (kernels_sym.hpp)
 // ------------------------------------------------------------------------------------------------
-static double sym_tol_deg();
+static double sym_tol_deg(double dflt);
 
 // Every column with lat > tol must have a partner with the opposite latitude (any longitude);
 // |lat| <= tol are equator columns (pairs without a southern partner).  Returns false if the grid is
 // not symmetric.  Pairs are ordered by their northern row so one operand still streams.
-static bool find_mirror_pairs(const double* lat, int64_t N, std::vector<int>& rowN, std::vector<int>& rowS) {
+static bool find_mirror_pairs(const double* lat, int64_t N, std::vector<int>& rowN, std::vector<int>& rowS, double tol_dflt) {
   if (N >= ((int64_t)1 << 31)) return false;
   // Two columns pair up when their latitudes are opposite to within `tol` degrees; the pair is then
   // treated as sitting exactly at +-(northern latitude), which perturbs the operator by
   // O(L^2 tol).  The default keeps that below the fp64 parity tolerance; TEMX_SYM_TOL_DEG widens
   // it for grids whose files carry noisier latitudes.
-  const double tol = sym_tol_deg();
+  const double tol = sym_tol_deg(tol_dflt);
   std::vector<int> north, south, eq;
   for (int64_t i = 0; i < N; ++i) {
     if (!(std::fabs(lat[i]) <= 90.0 + 1e-9)) return false;
@@ -613,12 +613,16 @@ static bool find_mirror_pairs(const double* lat, int64_t N, std::vector<int>& ro
 }
 
 
-static double sym_tol_deg() {
-  // Two columns share a latitude class (or pair up) when their |lat| agree to within `tol`
-  // degrees; the members are then treated as sitting exactly at the class latitude, which perturbs
-  // the operator by O(L^2 tol).  The default keeps that below the fp64 parity tolerance;
-  // TEMX_SYM_TOL_DEG widens it for grids whose files carry noisier latitudes.
-  double tol = 1e-12;
+static double sym_tol_deg(double dflt) {
+  // Two columns share a latitude class (or pair up) when their |lat| agree to within `tol` degrees; the members are
+  // then treated as sitting exactly at the class latitude (the mean of its members), which perturbs a basis row by
+  // about L tol (in radians) of its size.  The default, 1e-11 degrees, keeps that below 1e-11 -- a tenth of the fp64
+  // parity tolerance -- and covers what asin / round-off leave on grids whose latitudes are equal in exact
+  // arithmetic (the natural construction of the cubed sphere is off by ~1e-12 degrees at ne240; round 3 used 1e-12
+  // and a grid generator that mirrored the hemispheres bit for bit).  TEMX_LAT_TOL_F32 (fp32 fields: results are
+  // compared to 2e-5) widens it to 1e-8 degrees; TEMX_SYM_TOL_DEG in the environment sets it outright, for grids
+  // whose files carry noisier latitudes.
+  double tol = dflt;
   if (const char* e = getenv("TEMX_SYM_TOL_DEG")) {
     const double t = atof(e);
     if (t > 0.0 && t < 1e-3) tol = t;
@@ -636,9 +640,9 @@ struct ClassTables {
   int64_t ncls = 0, ngroups = 0, nbatch = 0;
 };
 
-static bool build_classes(const double* lat, int64_t N, ClassTables& ct) {
+static bool build_classes(const double* lat, int64_t N, ClassTables& ct, double tol_dflt) {
   if (N >= ((int64_t)1 << 27) || N < 64) return false;     // row indices live in 27 bits of a table entry
-  const double tol = sym_tol_deg();
+  const double tol = sym_tol_deg(tol_dflt);
   std::vector<int> order((size_t)N);
   for (int64_t i = 0; i < N; ++i) {
     if (!(std::fabs(lat[i]) <= 90.0 + 1e-9)) return false;
@@ -2122,6 +2126,7 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
   temx_plan* pl = new temx_plan();
   pl->device = device;
   pl->no_qr = (flags & TEMX_NO_QR) != 0;
+  const double tol_dflt = (flags & TEMX_LAT_TOL_F32) ? 1e-8 : 1e-11;   // degrees; see sym_tol_deg
   pl->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   pl->N = ncol;
   pl->nchunk = (ncol + 15) / 16;
@@ -2194,7 +2199,7 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
     const char* e1 = getenv("TEMX_NO_CLS");
     ClassTables ct;
     if ((!pl->large || pl->K <= 256) && !(flags & (TEMX_NO_SYMMETRY | TEMX_NO_CLASSES)) && !(e0 && e0[0] == '1') &&
-        !(e1 && e1[0] == '1') && build_classes(lat_deg_host, ncol, ct)) {
+        !(e1 && e1[0] == '1') && build_classes(lat_deg_host, ncol, ct, tol_dflt)) {
       if ((rc = upload(pl->crow, ct.crow.data(), ct.crow.size() * sizeof(int)))) return bail(rc);
 
       if ((rc = upload(pl->ccnt, ct.cnt.data(), ct.cnt.size() * 8))) return bail(rc);
@@ -2235,7 +2240,7 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
   if (!pl->cls) {
     const char* e = getenv("TEMX_NO_SYM");
     std::vector<int> rN, rS;
-    if (!pl->large && !(flags & TEMX_NO_SYMMETRY) && !(e && e[0] == '1') && find_mirror_pairs(lat_deg_host, ncol, rN, rS)) {
+    if (!pl->large && !(flags & TEMX_NO_SYMMETRY) && !(e && e[0] == '1') && find_mirror_pairs(lat_deg_host, ncol, rN, rS, tol_dflt)) {
       pl->npair = (int64_t)rN.size();
       pl->npg = (pl->npair + 3) / 4;
       pl->npg_alloc = ((pl->npg + SYM_PROJ_CH - 1) / SYM_PROJ_CH + 1) * SYM_PROJ_CH;   // whole chunks + 1 chunk

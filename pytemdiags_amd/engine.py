@@ -27,7 +27,7 @@ class Plan:
     """One plan per (device, native grid, output latitudes, L).  See include/temx.h."""
 
     def __init__(self, lat_deg, lat_out_deg, L, device=0, defer_finalize=False, symmetry=True, classes=True, qr=True,
-                 form=None):
+                 form=None, fp32_fields=False):
         self._h = C.c_void_p()
         self.lib = _lib.load()
         if isinstance(device, torch.device):
@@ -43,7 +43,8 @@ class Plan:
                                         plat, plat_out, (_lib.DEFER_FINALIZE if defer_finalize else 0)
                                         | (0 if symmetry else _lib.NO_SYMMETRY)
                                         | (0 if classes else _lib.NO_CLASSES)
-                                        | (0 if qr else _lib.NO_QR)))
+                                        | (0 if qr else _lib.NO_QR)
+                                        | (_lib.LAT_TOL_F32 if fp32_fields else 0)))
         if form is not None:
             self.configure(form=form)
 

@@ -45,8 +45,11 @@ class sph_zonal_averager:
 
     def __init__(self, lat, lat_out, L, weights=None, grid_name=None, grid_out_name=None,
                  ncoldim="ncol", overwrite=False, save_dest=None, debug=False, logfile=None,
-                 device=None):
+                 device=None, fp32_fields=False):
         self.L = L
+        # (not in the reference's signature) the arrays to be averaged are fp32: latitudes that agree to 1e-8 degrees
+        # share a basis row (include/temx.h, TEMX_LAT_TOL_F32)
+        self._fp32_fields = bool(fp32_fields)
         self.lat = _as_numpy(lat)                    # sph_zonal_mean.py:148-151
         self.lat_out = _as_numpy(lat_out)
         # the caller's weights as float64 (sum to 1); the reference scales its attribute by 4 pi only AFTER the
@@ -153,7 +156,8 @@ class sph_zonal_averager:
         if self._plan is not None:
             self._plan.close()
         self._cache = {}
-        self._plan = engine.Plan(self.lat, self.lat_out, self.L, device=self.device, defer_finalize=weighted)
+        self._plan = engine.Plan(self.lat, self.lat_out, self.L, device=self.device, defer_finalize=weighted,
+                                 fp32_fields=self._fp32_fields)
         if weighted:
             self._plan.set_weights(self._w_raw)
         if cached is not None:

@@ -23,11 +23,13 @@ def ncol_of_ne(ne: int) -> int:
     return 6 * ne * ne * 9 + 2
 
 
-def cubed_sphere_gll(ne: int):
+def cubed_sphere_gll(ne: int, mirror: bool = True):
     """Return (lat_deg, lon_deg) of the unique np=4 GLL nodes of an ne x ne x 6 cubed sphere.
 
     Points are sorted lexicographically by rounded (x, y, z) so the order is
-    deterministic but *unstructured* with respect to latitude.
+    deterministic but *unstructured* with respect to latitude.  ``mirror=False`` leaves the
+    latitudes as the construction gives them: equal across a latitude class only up to
+    round-off (~1e-12 degrees at ne240), the state real grid files are in.
     """
     gll = np.array([-1.0, -1.0 / np.sqrt(5.0), 1.0 / np.sqrt(5.0), 1.0])
     edges = np.linspace(-np.pi / 4, np.pi / 4, ne + 1)
@@ -53,12 +55,13 @@ def cubed_sphere_gll(ne: int):
     # The ideal grid is mirror symmetric about the equator, but the 12-digit rounding above resolves
     # the two face-copies of an edge node independently in each hemisphere (1e-12-level asymmetry at
     # ne240).  Rebuild the south as the exact mirror of the north so latitudes are bitwise +-.
-    north = P[P[:, 2] > 1e-9]
-    eq = P[np.abs(P[:, 2]) <= 1e-9].copy()
-    eq[:, 2] = 0.0
-    eq /= np.linalg.norm(eq, axis=1, keepdims=True)
-    assert 2 * north.shape[0] + eq.shape[0] == P.shape[0]
-    P = np.concatenate([north, north * np.array([1.0, 1.0, -1.0]), eq], axis=0)
+    if mirror:
+        north = P[P[:, 2] > 1e-9]
+        eq = P[np.abs(P[:, 2]) <= 1e-9].copy()
+        eq[:, 2] = 0.0
+        eq /= np.linalg.norm(eq, axis=1, keepdims=True)
+        assert 2 * north.shape[0] + eq.shape[0] == P.shape[0]
+        P = np.concatenate([north, north * np.array([1.0, 1.0, -1.0]), eq], axis=0)
     P = P[np.lexsort((np.round(P[:, 2], 12), np.round(P[:, 1], 12), np.round(P[:, 0], 12)))]
     lat = np.rad2deg(np.arcsin(np.clip(P[:, 2], -1.0, 1.0)))
     lon = np.mod(np.rad2deg(np.arctan2(P[:, 1], P[:, 0])), 360.0)

@@ -61,7 +61,8 @@ class TEMDiagnostics:
         # ---- zonal averaging object (tem_diagnostics.py:243-249) ----
         self.ZM = sph_zonal_averager(self._lat_native_np, self._lat_zm, self.L, grid_name=grid_name,
                                      grid_out_name=zm_grid_name, save_dest=map_save_dest,
-                                     debug=debug_level > 1, overwrite=overwrite_map, device=self._device)
+                                     debug=debug_level > 1, overwrite=overwrite_map, device=self._device,
+                                     fp32_fields=str(self._work_dtype) == "torch.float32")
         if self.ZM.Y0 is None or self.ZM.Y0p is None:
             self.ZM.sph_compute_matrices(overwrite=overwrite_map)
         self._zonal_mean = self.ZM.sph_zonal_mean

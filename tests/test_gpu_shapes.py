@@ -833,3 +833,45 @@ def test_row_map_kernels_on_uneven_classes(monkeypatch, dtype, single):
         e = fieldnorm_err(tres[k].cpu().numpy(), getattr(ref, n)(0))
         assert e <= tol, (n, e)
     plan.close()
+
+
+def test_latitude_noise_of_real_grids_keeps_the_class_sweeps():
+    """VERDICT r03 #6.  (a) The natural construction of the cubed sphere (no bit-for-bit mirror rebuild: latitudes of
+    a class agree to round-off only) stays on the latitude-class sweeps with the default tolerance and holds the
+    fp64 parity tolerance.  (b) fp32 fields: a latitude coordinate with 3e-9 degrees of noise -- far outside the fp64
+    tolerance -- keeps the class sweeps through TEMX_LAT_TOL_F32 (which the front end sets for fp32 inputs) and holds
+    2e-5; without the flag the same grid falls back to another form.  (sph_zonal_mean.py:360-363: Y depends on
+    latitude only.)"""
+    import os
+    from oracle import tem_oracle as orc
+    from pytemdiags_amd import _lib, engine, synth
+    if any(os.environ.get(k) for k in ("TEMX_NO_SYM", "TEMX_NO_CLS", "TEMX_SYM_TOL_DEG")):
+        pytest.skip("the environment fixes the sweeps / the tolerance")
+    ne, nlev, nt = 16, 8, 3
+    lat, lon = synth.cubed_sphere_gll(ne, mirror=False)
+    lat_m, _ = synth.cubed_sphere_gll(ne)
+    assert lat.size == lat_m.size
+    plev = synth.pressure_levels(nlev)
+    f = synth.analytic_fields(lat, lon, plev, nt, seed=5)
+    ref = orc.TEMOracle(*f, lat, plev, mode="factorised")
+    plan = engine.Plan(lat, ref.lat, 50)
+    assert plan.sweep_mode == 2
+    plan.set_tem(nlev, nt, plev * 100)
+    res, _ = plan.tem_run(*[torch.as_tensor(x, device="cuda:0") for x in f])
+    for i, n in enumerate(_lib.RESULT_NAMES):
+        assert fieldnorm_err(res[i].cpu().numpy(), getattr(ref, n)()) <= 1e-10, n
+    plan.close()
+    rng = np.random.default_rng(3)
+    latn = lat_m + rng.uniform(-3e-9, 3e-9, lat_m.size)
+    f32 = synth.analytic_fields(latn, lon, plev, nt, seed=5, dtype=np.float32)
+    ref = orc.TEMOracle(*f32, latn, plev, mode="factorised")
+    p0 = engine.Plan(latn, ref.lat, 50)
+    assert p0.sweep_mode != 2                                    # fp64 tolerance: no classes on this coordinate
+    p0.close()
+    plan = engine.Plan(latn, ref.lat, 50, fp32_fields=True)
+    assert plan.sweep_mode == 2
+    plan.set_tem(nlev, nt, plev * 100)
+    res, _ = plan.tem_run(*[torch.as_tensor(x, device="cuda:0") for x in f32])
+    for i, n in enumerate(_lib.RESULT_NAMES):
+        assert fieldnorm_err(res[i].cpu().numpy(), np.asarray(getattr(ref, n)(), np.float64)) <= 2e-5, n
+    plan.close()
