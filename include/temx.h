@@ -287,19 +287,23 @@ int temx_tem_run(temx_plan* plan, const void* ua, const void* va, const void* ta
  * temx_tem_run on such a plan is the three calls with nslices = 1.  After a tail on a proper slice the plan's
  * coefficients describe that slice only: the staged entry points for the whole run (temx_tem_stage3,
  * temx_tracer_stage2 ..., temx_tem_eddy) return TEMX_ESTATE until a whole-run stage 1 / 2 has run again.
- * The tracer (after temx_tem_os_tail on the same snapshots, same va / wap): temx_tracer_os_prepass (Asq[KR][D],
- * all-reduce), temx_tracer_os_sweep (projq: (2L+1) + 2 (L+1) rows, sliced like proj), temx_tracer_os_tail. */
+ * Tracers (after temx_tem_os_tail on the same snapshots, same va / wap), nq = 1 or 2 per sweep -- two tracers share
+ * one read of v and omega: temx_tracers_os_prepass (Asq[nq][KR][D], all-reduce), temx_tracers_os_sweep (projq:
+ * nq (2L+1) + 2 nq (L+1) rows -- the q's, then q1 v, q1 omega, q2 v, q2 omega --, sliced like proj),
+ * temx_tracers_os_tail (tres_host / tzon_host: host arrays of nq device pointers, [TEMX_NTRES][M][nlev][nts] /
+ * [TEMX_NTZON][M][nlev][nts] each; tzon_host may be NULL).  q_host: host array of nq device pointers. */
 int temx_tem_os_prepass(temx_plan* plan, const void* ua, const void* va, const void* ta, const void* wap, int dtype,
                         double* As, void* stream);
 int temx_tem_os_sweep(temx_plan* plan, const void* ua, const void* va, const void* ta, const void* wap, int dtype,
                       const double* As, int nslices, double* proj, void* stream);
 int temx_tem_os_tail(temx_plan* plan, const double* proj_slice, int64_t t0, int64_t nts, double* results,
                      double* zonal, void* stream);
-int temx_tracer_os_prepass(temx_plan* plan, const void* q, const void* va, const void* wap, int dtype, double* Asq,
-                           void* stream);
-int temx_tracer_os_sweep(temx_plan* plan, const void* q, const void* va, const void* wap, int dtype,
-                         const double* Asq, int nslices, double* projq, void* stream);
-int temx_tracer_os_tail(temx_plan* plan, const double* projq_slice, double* tres, double* tzon, void* stream);
+int temx_tracers_os_prepass(temx_plan* plan, int nq, const void* const* q_host, const void* va, const void* wap,
+                            int dtype, double* Asq, void* stream);
+int temx_tracers_os_sweep(temx_plan* plan, int nq, const void* const* q_host, const void* va, const void* wap,
+                          int dtype, const double* Asq, int nslices, double* projq, void* stream);
+int temx_tracers_os_tail(temx_plan* plan, int nq, const double* projq_slice, double* const* tres_host,
+                         double* const* tzon_host, void* stream);
 
 /* The same time-sliced tail for raw sums of ANY form of the sweeps (class-sum form, paired, generic):
  * B4s [4][K][nlev][nts] and B3s [3][K][nlev][nts] (summed over the ranks) -> stages 2b + 3 for the snapshots
@@ -350,6 +354,12 @@ int temx_tracer_stage1_sums(temx_plan* plan, const void* q, const void* va, cons
 int temx_tracer_stage2_from_sums(temx_plan* plan, const double* Bq, double* Bq2, void* stream);
 int temx_tracer_run(temx_plan* plan, const void* q, const void* va, const void* wap, int dtype,
                     double* tres, double* tzon, void* stream);
+/* nq tracers of one TEM run (the reference takes a LIST of tracers, tem_diagnostics.py:281-301, 532-538, 560-570).
+ * After a single-sweep temx_tem_run they are swept in PAIRS: (q1, q2, v, omega) read once -- the traffic of the TEM
+ * sweep for two tracers instead of three quarters of it for each; a last odd one, and every tracer on any other path,
+ * goes through temx_tracer_run.  q_host, tres_host, tzon_host (may be NULL): host arrays of nq device pointers. */
+int temx_tracers_run(temx_plan* plan, int nq, const void* const* q_host, const void* va, const void* wap, int dtype,
+                     double* const* tres_host, double* const* tzon_host, void* stream);
 /* TEM and ONE tracer that is known up front (TEMDiagnostics(q=...), tem_diagnostics.py:241-259 runs both in
  * its constructor): temx_tem_tracer_stage1 is temx_tem_stage1 + temx_tracer_stage1_sums in ONE sweep over
  * (u, v, T, omega, q) -- 40 bytes per grid point instead of 32 + 24 -- with the four waves of a workgroup

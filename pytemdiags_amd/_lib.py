@@ -69,9 +69,10 @@ SIGNATURES = [
     ("temx_tem_os_prepass", _i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     ("temx_tem_os_sweep", _i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     ("temx_tem_os_tail", _i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
-    ("temx_tracer_os_prepass", _i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
-    ("temx_tracer_os_sweep", _i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
-    ("temx_tracer_os_tail", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("temx_tracers_os_prepass", _i, [_vp, _i, C.POINTER(_vp), _vp, _vp, _i, _vp, _vp]),
+    ("temx_tracers_os_sweep", _i, [_vp, _i, C.POINTER(_vp), _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    ("temx_tracers_os_tail", _i, [_vp, _i, _vp, C.POINTER(_vp), C.POINTER(_vp), _vp]),
+    ("temx_tracers_run", _i, [_vp, _i, C.POINTER(_vp), _vp, _vp, _i, C.POINTER(_vp), C.POINTER(_vp), _vp]),
     ("temx_tem_tail_from_sums", _i, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     ("temx_time_slices", _i, [_vp, _vp, _i64, _i, _vp, _vp]),
     ("temx_tem_eddy", _i, [_vp, _vp, _vp, _vp, _vp, _i, C.POINTER(_vp), _vp]),

@@ -304,15 +304,25 @@ __device__ __forceinline__ constexpr int symx_harm(int tb, int i) {
 // KIND 1: tracer  fields (q, v, omega): only q is projected to degree 2L (the projections of v and omega are
 //                 those of the TEM run, whose references for v and omega must be handed over again); products q v, q omega
 template <int KIND> struct OsKind;
+//                 those of the TEM run, whose references for v and omega must be handed over again); products q v, q omega
+// KIND 3: two tracers  fields (q1, q2, v, omega): q1 and q2 projected to degree 2L; products q1 v, q1 omega, q2 v, q2 omega.
+//                 One read of v and omega serves two tracers (tem_diagnostics.py:281-301 takes a LIST of tracers):
+//                 2 x 26 + 4 x 14 = 108 accumulators; NPR of the products keep theirs in registers (the fields need
+//                 half the registers of KIND 0), the others in LDS as before.
 template <> struct OsKind<0> {
-  static constexpr int NF = 4, NFX = 4, NP = 3, TF = 2, TP = 2;
+  static constexpr int NF = 4, NFX = 4, NP = 3, TF = 2, TP = 2, NPR = 0;
   __host__ __device__ static constexpr int pa(int k) { return k == 2 ? 1 : 0; }
   __host__ __device__ static constexpr int pb(int k) { return k == 0 ? 1 : (k == 1 ? 3 : 2); }
 };
 template <> struct OsKind<1> {
-  static constexpr int NF = 3, NFX = 1, NP = 2, TF = -1, TP = -1;
+  static constexpr int NF = 3, NFX = 1, NP = 2, TF = -1, TP = -1, NPR = 0;
   __host__ __device__ static constexpr int pa(int) { return 0; }
   __host__ __device__ static constexpr int pb(int k) { return k == 0 ? 1 : 2; }
+};
+template <> struct OsKind<3> {
+  static constexpr int NF = 4, NFX = 2, NP = 4, TF = -1, TP = -1, NPR = 2;
+  __host__ __device__ static constexpr int pa(int k) { return k >> 1; }
+  __host__ __device__ static constexpr int pb(int k) { return 2 + (k & 1); }
 };
 
 #ifndef TEMX_OS_SKIP
@@ -690,11 +700,12 @@ sweep_osr_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
   constexpr int MB = CLS_MB;
   constexpr int NCH = 4;
   constexpr int NV = 2 * (NF + NP);           // exchanged per (class, column): side means, central co-moments
+  constexpr int NPR = KD::NPR, NPL = NP - NPR; // product accumulators in registers / in LDS
   static_assert(NBR <= TBS && TBS <= TBX, "reference degree <= L <= 2L");
   static_assert(YJ <= 2, "Y quarter per thread");
   static_assert((PD - 1) * CLS_MB * KD::NF + (CLS_MB - 1) * KD::NF + 2 <= 63, "the ring is counted in vmcnt (6 bits)");
   // [2][YE] Y blocks | [16] member counts | [4 waves][NF][2 NBR][64] reference operands |
-  // [4 waves][NP][2 TBS][64] product accumulators | [NV][4 classes][64 columns] exchange
+  // [4 waves][NP - NPR][2 TBS][64] product accumulators | [NV][4 classes][64 columns] exchange
   extern __shared__ double lds[];
   int split, dq;
   if (!wg_work((ndt + 3) / 4, nsplit, split, dq)) return;
@@ -717,13 +728,18 @@ sweep_osr_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
   double* ybase = lds;
   double* cn = lds + 2 * YE;
   double* cb = lds + 2 * YE + 16 + wave * (NF * 2 * NBR * 64) + lane;
-  double* apl = lds + 2 * YE + 16 + 4 * (NF * 2 * NBR * 64) + wave * (NP * 2 * TBS * 64) + lane;
-  double* ex = lds + 2 * YE + 16 + 4 * (NF * 2 * NBR * 64) + 4 * (NP * 2 * TBS * 64);
+  double* apl = lds + 2 * YE + 16 + 4 * (NF * 2 * NBR * 64) + wave * (NPL * 2 * TBS * 64) + lane;
+  double* ex = lds + 2 * YE + 16 + 4 * (NF * 2 * NBR * 64) + 4 * (NPL * 2 * TBS * 64);
   double* exw = ex + wave * 64 + lane;                   // [v][my class][my column]
   const double* exr = ex + g * 64 + wave * 16 + c;       // [v][class g][column of my d-tile]
   const double sth = (KD::TF >= 0 && colscale != nullptr) ? colscale[colr] : 1.0;
 #pragma unroll
-  for (int i = 0; i < NP * 2 * TBS; ++i) apl[i * 64] = 0.0;
+  for (int i = 0; i < NPL * 2 * TBS; ++i) apl[i * 64] = 0.0;
+  double apr[NPR > 0 ? NPR : 1][2 * TBS];
+#pragma unroll
+  for (int k = 0; k < (NPR > 0 ? NPR : 1); ++k)
+#pragma unroll
+    for (int t = 0; t < 2 * TBS; ++t) apr[k][t] = 0.0;
 #pragma unroll
   for (int f = 0; f < NF; ++f)
 #pragma unroll
@@ -786,13 +802,17 @@ sweep_osr_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
       const int tp = t < TBX ? t : t - TBX;
       if (tp < TBS) {
         const int ta = t < TBX ? tp : TBS + tp;
-        double v[NP];
 #pragma unroll
-        for (int k = 0; k < NP; ++k) v[k] = apl[(k * 2 * TBS + ta) * 64];
+        for (int k = 0; k < NPR; ++k) apr[k][ta] = TEMX_MFMA4(ya, dP[k][t < TBX ? 0 : 1], apr[k][ta]);
+        if constexpr (NPL > 0) {
+          double v[NPL > 0 ? NPL : 1];
 #pragma unroll
-        for (int k = 0; k < NP; ++k) v[k] = TEMX_MFMA4(ya, dP[k][t < TBX ? 0 : 1], v[k]);
+          for (int k = 0; k < NPL; ++k) v[k] = apl[(k * 2 * TBS + ta) * 64];
 #pragma unroll
-        for (int k = 0; k < NP; ++k) apl[(k * 2 * TBS + ta) * 64] = v[k];
+          for (int k = 0; k < NPL; ++k) v[k] = TEMX_MFMA4(ya, dP[NPR + k][t < TBX ? 0 : 1], v[k]);
+#pragma unroll
+          for (int k = 0; k < NPL; ++k) apl[(k * 2 * TBS + ta) * 64] = v[k];
+        }
       }
     }
   };
@@ -982,7 +1002,7 @@ sweep_osr_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
 #pragma unroll
       for (int t = 0; t < 2 * TBS; ++t) {
         const int l = sym_harm<TBS>(t, g);
-        if (l < K) pp[(((int64_t)split * NP + k) * K + l) * D + d] = apl[(k * 2 * TBS + t) * 64];
+        if (l < K) pp[(((int64_t)split * NP + k) * K + l) * D + d] = k < NPR ? apr[k < NPR ? k : 0][t] : apl[((k < NPR ? 0 : k - NPR) * 2 * TBS + t) * 64];
       }
   }
 }
@@ -1014,11 +1034,12 @@ sweep_os2_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
   constexpr int MB = CLS_MB;
   constexpr int NCH = 2;
   constexpr int NV = NF + NP;                 // exchanged per (class side, column): mean of each field, central co-moments
+  constexpr int NPR = KD::NPR, NPL = NP - NPR; // product accumulators in registers / in LDS
   static_assert(NBR <= TBS && TBS <= TBX, "reference degree <= L <= 2L");
   static_assert(YE <= 512, "one Y element per thread");
   static_assert((PD - 1) * MB * NF + (MB - 1) * NF + 1 <= 63, "the ring is counted in vmcnt (6 bits)");
   // [2][YE] Y blocks | [16] member counts | [4 d-tiles][NF][2 NBR][64] reference operands |
-  // [8 waves][NP][TBS][64] product accumulators | [NV][8 class sides][64 columns] exchange
+  // [8 waves][NP - NPR][TBS][64] product accumulators | [NV][8 class sides][64 columns] exchange
   extern __shared__ double lds[];
   int split, dq;
   if (!wg_work((ndt + 3) / 4, nsplit, split, dq)) return;
@@ -1046,13 +1067,18 @@ sweep_os2_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
   double* ybase = lds;
   double* cn = lds + 2 * YE;
   double* cb = lds + 2 * YE + 16 + tl * (NF * 2 * NBR * 64) + lane;
-  double* apl = lds + 2 * YE + 16 + 4 * (NF * 2 * NBR * 64) + wave * (NP * TBS * 64) + lane;
-  double* ex = lds + 2 * YE + 16 + 4 * (NF * 2 * NBR * 64) + 8 * (NP * TBS * 64);
+  double* apl = lds + 2 * YE + 16 + 4 * (NF * 2 * NBR * 64) + wave * (NPL * TBS * 64) + lane;
+  double* ex = lds + 2 * YE + 16 + 4 * (NF * 2 * NBR * 64) + 8 * (NPL * TBS * 64);
   double* exw = ex + wave * 64 + lane;                   // [v][my class side][my column]
   const double* exr = ex + g * 64 + tl * 16 + c;         // [v][north side of class g][column of my d-tile]; south: + 256
   const double sth = (KD::TF >= 0 && colscale != nullptr) ? colscale[colr] : 1.0;
 #pragma unroll
-  for (int i = 0; i < NP * TBS; ++i) apl[i * 64] = 0.0;
+  for (int i = 0; i < NPL * TBS; ++i) apl[i * 64] = 0.0;
+  double apr[NPR > 0 ? NPR : 1][TBS];
+#pragma unroll
+  for (int k = 0; k < (NPR > 0 ? NPR : 1); ++k)
+#pragma unroll
+    for (int t = 0; t < TBS; ++t) apr[k][t] = 0.0;
   if (par == 0) {
 #pragma unroll
     for (int f = 0; f < NF; ++f)
@@ -1111,13 +1137,17 @@ sweep_os2_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
 #pragma unroll
       for (int f = 0; f < NFX; ++f) ax[f][t] = TEMX_MFMA4(ya, dS[f], ax[f][t]);
       if (t < TBS) {                          // the product blocks are the first TBS of the parity
-        double v[NP];
 #pragma unroll
-        for (int k = 0; k < NP; ++k) v[k] = apl[(k * TBS + t) * 64];
+        for (int k = 0; k < NPR; ++k) apr[k][t] = TEMX_MFMA4(ya, dP[k], apr[k][t]);
+        if constexpr (NPL > 0) {
+          double v[NPL > 0 ? NPL : 1];
 #pragma unroll
-        for (int k = 0; k < NP; ++k) v[k] = TEMX_MFMA4(ya, dP[k], v[k]);
+          for (int k = 0; k < NPL; ++k) v[k] = apl[(k * TBS + t) * 64];
 #pragma unroll
-        for (int k = 0; k < NP; ++k) apl[(k * TBS + t) * 64] = v[k];
+          for (int k = 0; k < NPL; ++k) v[k] = TEMX_MFMA4(ya, dP[NPR + k], v[k]);
+#pragma unroll
+          for (int k = 0; k < NPL; ++k) apl[(k * TBS + t) * 64] = v[k];
+        }
       }
     }
   };
@@ -1271,7 +1301,7 @@ sweep_os2_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
 #pragma unroll
       for (int t = 0; t < TBS; ++t) {
         const int l = 2 * (4 * t + g) + par;
-        if (l < K) pp[(((int64_t)split * NP + k) * K + l) * D + d] = apl[(k * TBS + t) * 64];
+        if (l < K) pp[(((int64_t)split * NP + k) * K + l) * D + d] = k < NPR ? apr[k < NPR ? k : 0][t] : apl[((k < NPR ? 0 : k - NPR) * TBS + t) * 64];
       }
   }
 }

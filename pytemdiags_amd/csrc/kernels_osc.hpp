@@ -150,11 +150,11 @@ osc_fields_kernel(OscFieldsIn in, OscMats m, int K, int KX, int KR, int NQ, int6
 
 // per pair p: the synthesised fields a = pa(p), b = pb(p) ([NQ][Dt] each) and the projection of their product [K][Dt]
 struct OscPairsIn {
-  const double* At_a[3];
-  const double* At_b[3];
-  const double* ab_a[3];
-  const double* ab_b[3];
-  const double* P[3];
+  const double* At_a[4];
+  const double* At_b[4];
+  const double* ab_a[4];
+  const double* ab_b[4];
+  const double* P[4];
 };
 
 template <int NBK>

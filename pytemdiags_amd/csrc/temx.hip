@@ -146,7 +146,7 @@ struct temx_plan {
   // contraction of the single sweep on the matrix cores (kernels_osc.hpp): host copies of its matrices, their 4x4
   // blocks on the device (one buffer), the synthesised fields At / ab [4][NQ][D] (kept: the tracer pairs with v, omega)
   std::vector<double> h_T, h_Ginv, h_G, h_Yq;
-  DevBuf oscblk, osAt, osAb, osAtq, osAbq;
+  DevBuf oscblk, osAt, osAb, osAtq, osAbq, Bqp;
   OscMats osc{};
   bool osc_lds = false;                // TEMX_OPT_OS_CONTRACT = 1 / TEMX_OS_CONTRACT=lds: the round-3 LDS form (A/B)
   int opt_os_contract = -1;
@@ -1683,7 +1683,10 @@ static int launch_sweep_os_t(temx_plan* pl, const FieldPtrs<4>& fp, bool sub, co
   double* pp = partial + (int64_t)sp.nsplit * KD::NFX * pl->KX * pl->D;
 #define TEMX_LOS(TBSv, TBXv)                                                                                        \
   do {                                                                                                              \
-    if (tile_map) {                                                                                                 \
+    if constexpr (KIND == 3) {                                                                                      \
+      if (tile_map) return fail(TEMX_EUNSUPPORTED, "two tracers per sweep: row-map sweeps only");                   \
+    }                                                                                                               \
+    if constexpr (KIND != 3) if (tile_map) {                                                                        \
       auto kern = sweep_os_kernel<T, TBSv, TBXv, NBR, PDv, KIND, DF>;                                               \
       const size_t lds = ((size_t)4 * (DF ? 2 : 1) * 2 * TBXv * 16 + (size_t)4 * KD::NF * 2 * NBR * 64 +            \
                           (size_t)4 * KD::NP * 2 * TBSv * 64) * 8;                                                  \
@@ -1692,10 +1695,12 @@ static int launch_sweep_os_t(temx_plan* pl, const FieldPtrs<4>& fp, bool sub, co
       hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->D, pl->K, pl->KX, sub ? pl->ycx_s.d() : pl->ycx.d(),   \
                          static_cast<const int4*>(sub ? pl->crow_s.p : pl->crow.p), cuts, pl->colscale.d(), rho,    \
                          pl->KR, px, pp, sp.nsplit, sp.ndt);                                                        \
-    } else if (sizeof(T) == 4) {   /* fp32 inputs: two waves per SIMD (kernels_op2.hpp, sweep_os2_kernel) */       \
+      break;                                                                                                        \
+    }                                                                                                               \
+    if (sizeof(T) == 4) {   /* fp32 inputs: two waves per SIMD (kernels_op2.hpp, sweep_os2_kernel) */              \
       auto kern = sweep_os2_kernel<float, TBSv, TBXv, NBR, 2, KIND>;                                                \
       const size_t lds = ((size_t)2 * 2 * TBXv * 16 + 16 + (size_t)4 * KD::NF * 2 * NBR * 64 +                      \
-                          (size_t)8 * KD::NP * TBSv * 64 + (size_t)(KD::NF + KD::NP) * 512) * 8;                    \
+                          (size_t)8 * (KD::NP - KD::NPR) * TBSv * 64 + (size_t)(KD::NF + KD::NP) * 512) * 8;        \
       static std::atomic<uint64_t> attr_set{0};                                                                     \
       if (int rc_ = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(kern), (int)lds)) return rc_; \
       const int si = sub ? 1 : 0;                                                                                   \
@@ -1706,7 +1711,7 @@ static int launch_sweep_os_t(temx_plan* pl, const FieldPtrs<4>& fp, bool sub, co
     } else {                                                                                                        \
       auto kern = sweep_osr_kernel<double, TBSv, TBXv, NBR, 2, KIND>;                                               \
       const size_t lds = ((size_t)2 * 2 * TBXv * 16 + 16 + (size_t)4 * KD::NF * 2 * NBR * 64 +                      \
-                          (size_t)4 * KD::NP * 2 * TBSv * 64 + (size_t)2 * (KD::NF + KD::NP) * 256) * 8;            \
+                          (size_t)4 * (KD::NP - KD::NPR) * 2 * TBSv * 64 + (size_t)2 * (KD::NF + KD::NP) * 256) * 8; \
       static std::atomic<uint64_t> attr_set{0};                                                                     \
       if (int rc_ = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(kern), (int)lds)) return rc_; \
       hipLaunchKernelGGL(kern, grid, block, lds, st, fp, pl->D, pl->K, pl->KX, sub ? pl->ycx_s.d() : pl->ycx.d(),   \
@@ -1890,105 +1895,126 @@ static int tem_run_os(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, double* 
 
 static int tracer_ws(temx_plan* pl);
 
-// Tracer in the single-sweep form: (q, v, omega) read once, no class sums.  The degree-2L projections and the
-// references of v and omega are those the TEM run left in the plan (os_valid): the same v and omega must be
-// handed over.  q gets its own reference from a pre-pass, is projected to degree 2L, q v and q omega to degree L.
-// The same three steps as the TEM run; Asq[KR][D], projq = [KX + 2 K] rows.
-static int tracer_os_ws(temx_plan* pl) {
+// Tracers in the single-sweep form: (q, v, omega) -- or (q1, q2, v, omega): one read of v and omega for two tracers --
+// read once, no class sums.  The degree-2L projections and the references of v and omega are those the TEM run left in
+// the plan (os_valid): the same v and omega must be handed over.  Each q gets its own reference from a pre-pass, is
+// projected to degree 2L, q v and q omega to degree L.  The same three steps as the TEM run; for nq tracers:
+// Asq[nq][KR][D], projq = nq KX + 2 nq K rows (the q's, then q1 v, q1 omega, q2 v, q2 omega).
+static int tracer_os_ws(temx_plan* pl, int nq) {
   const int64_t D = pl->D;
   int rc;
   if ((rc = tracer_ws(pl))) return rc;
-  if ((rc = pl->Axq.ensure((size_t)(pl->KX + 2 * pl->K + pl->KR) * D * 8))) return rc;   // projections, then the pre-pass sums
-  if ((rc = pl->osAtq.ensure((size_t)pl->NQ * D * 8))) return rc;
-  if ((rc = pl->osAbq.ensure((size_t)pl->NQ * D * 8))) return rc;
-  return pl->rho_t.ensure((size_t)3 * pl->KR * D * 8);
+  if ((rc = pl->Axq.ensure((size_t)nq * (pl->KX + 2 * pl->K + pl->KR) * D * 8))) return rc;   // projections, then the pre-pass sums
+  if ((rc = pl->osAtq.ensure((size_t)nq * pl->NQ * D * 8))) return rc;
+  if ((rc = pl->osAbq.ensure((size_t)nq * pl->NQ * D * 8))) return rc;
+  if ((rc = pl->Bqp.ensure((size_t)nq * 3 * pl->K * D * 8))) return rc;                       // raw sums of the q's, then of the products
+  return pl->rho_t.ensure((size_t)4 * pl->KR * D * 8);
 }
 
-static int tracer_os_prepass(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, double* Asq, hipStream_t st) {
+// fp: (q, v, omega, -) for one tracer, (q1, q2, v, omega) for two
+static int tracer_os_prepass(temx_plan* pl, int nq, const FieldPtrs<4>& fp, int dtype, double* Asq, hipStream_t st) {
   int rc;
   const int64_t D = pl->D;
-  if ((rc = tracer_os_ws(pl))) return rc;
+  if ((rc = tracer_os_ws(pl, nq))) return rc;
   pl->tq_valid = false;
-  // (the references of v, omega do not matter here: only q's projection is used)
-  if ((rc = launch_sweep_os<1>(pl, fp, dtype, true, pl->rho0.d(), pl->partial.d(), pl->sp_os_s, st))) return rc;
-  const int64_t n = (int64_t)pl->KR * D;
+  // (the references of v, omega do not matter here: only the projections of the q's are used)
+  rc = nq == 2 ? launch_sweep_os<3>(pl, fp, dtype, true, pl->rho0.d(), pl->partial.d(), pl->sp_os_s, st)
+               : launch_sweep_os<1>(pl, fp, dtype, true, pl->rho0.d(), pl->partial.d(), pl->sp_os_s, st);
+  if (rc) return rc;
+  const int64_t n = (int64_t)nq * pl->KR * D;
   hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pl->partial.d(), pl->sp_os_s.nsplit,
-                     (int64_t)pl->KX * D, 1, pl->KX, pl->KR, D, Asq, static_cast<int*>(pl->flag.p));
+                     (int64_t)nq * pl->KX * D, nq, pl->KX, pl->KR, D, Asq, static_cast<int*>(pl->flag.p));
   HIPCHK(hipGetLastError());
   return TEMX_OK;
 }
 
-static int tracer_os_sweep(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, const double* Asq, int nsl, double* projq, hipStream_t st) {
+static int tracer_os_sweep(temx_plan* pl, int nq, const FieldPtrs<4>& fp, int dtype, const double* Asq, int nsl, double* projq,
+                           hipStream_t st) {
   int rc;
   const int64_t D = pl->D, KXD = (int64_t)pl->KX * D, KD = (int64_t)pl->K * D, KRD = (int64_t)pl->KR * D;
-  if ((rc = tracer_os_ws(pl))) return rc;
+  if ((rc = tracer_os_ws(pl, nq))) return rc;
   pl->tq_valid = false;
-  hipLaunchKernelGGL(os_ref_solve_kernel, dim3((unsigned)((D + 255) / 256), 1), dim3(256), 0, st, Asq, pl->KR, pl->KR, D,
+  // references: (rho_q, rho_v, rho_omega) / (rho_q1, rho_q2, rho_v, rho_omega), v and omega as the TEM run fitted them
+  hipLaunchKernelGGL(os_ref_solve_kernel, dim3((unsigned)((D + 255) / 256), nq), dim3(256), 0, st, Asq, pl->KR, pl->KR, D,
                      pl->Gsinv.d(), pl->rho_t.d());
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(pl->rho_t.d() + KRD, pl->rho.d() + 1 * KRD, (size_t)KRD * 8, hipMemcpyDeviceToDevice, st));   // v
-  HIPCHK(hipMemcpyAsync(pl->rho_t.d() + 2 * KRD, pl->rho.d() + 3 * KRD, (size_t)KRD * 8, hipMemcpyDeviceToDevice, st));   // omega
-  if ((rc = launch_sweep_os<1>(pl, fp, dtype, false, pl->rho_t.d(), pl->partial.d(), pl->sp_os, st))) return rc;
-  const int64_t rows = (int64_t)pl->KX + 2 * pl->K;
-  if ((rc = launch_reduce(pl, pl->partial.d(), pl->sp_os.nsplit, KXD, projq, st, -1, nullptr, slice_map(pl, nsl, rows, 0)))) return rc;
-  return launch_reduce(pl, pl->partial.d() + (int64_t)pl->sp_os.nsplit * KXD, pl->sp_os.nsplit, 2 * KD, nsl > 1 ? projq : projq + KXD, st,
-                       -1, nullptr, slice_map(pl, nsl, rows, pl->KX));
+  HIPCHK(hipMemcpyAsync(pl->rho_t.d() + nq * KRD, pl->rho.d() + 1 * KRD, (size_t)KRD * 8, hipMemcpyDeviceToDevice, st));         // v
+  HIPCHK(hipMemcpyAsync(pl->rho_t.d() + (nq + 1) * KRD, pl->rho.d() + 3 * KRD, (size_t)KRD * 8, hipMemcpyDeviceToDevice, st));   // omega
+  rc = nq == 2 ? launch_sweep_os<3>(pl, fp, dtype, false, pl->rho_t.d(), pl->partial.d(), pl->sp_os, st)
+               : launch_sweep_os<1>(pl, fp, dtype, false, pl->rho_t.d(), pl->partial.d(), pl->sp_os, st);
+  if (rc) return rc;
+  const int64_t rows = (int64_t)nq * (pl->KX + 2 * pl->K);
+  if ((rc = launch_reduce(pl, pl->partial.d(), pl->sp_os.nsplit, nq * KXD, projq, st, -1, nullptr, slice_map(pl, nsl, rows, 0)))) return rc;
+  return launch_reduce(pl, pl->partial.d() + (int64_t)pl->sp_os.nsplit * nq * KXD, pl->sp_os.nsplit, 2 * nq * KD,
+                       nsl > 1 ? projq : projq + nq * KXD, st, -1, nullptr, slice_map(pl, nsl, rows, (int64_t)nq * pl->KX));
 }
 
-// the tracer's tail for the snapshots the TEM tail worked on (set_tail): projq_s [KX + 2 K][nlev][tnt]
-static int tracer_os_tail(temx_plan* pl, const double* projq_s, double* tres, double* tzon, hipStream_t st) {
+// the tracers' tail for the snapshots the TEM tail worked on (set_tail): projq_s [nq KX + 2 nq K][nlev][tnt]
+static int tracer_os_tail(temx_plan* pl, int nq, const double* projq_s, double* const* tres, double* const* tzon, hipStream_t st) {
   int rc;
-  const int64_t Dt = pl->tD, KXD = (int64_t)pl->KX * Dt, KRD = (int64_t)pl->KR * pl->D;
-  {
+  const int64_t Dt = pl->tD, KXD = (int64_t)pl->KX * Dt, KDt = (int64_t)pl->K * Dt, KRD = (int64_t)pl->KR * pl->D;
+  double* Bq = pl->Bqp.d();                    // [nq][K][Dt]
+  double* Bq2 = pl->Bqp.d() + nq * KDt;        // [2 nq][K][Dt]
+  if (pl->osc_lds) {
+    if (nq != 1) return fail(TEMX_EUNSUPPORTED, "two tracers per sweep need the contraction on the matrix cores (TEMX_OPT_OS_CONTRACT = 0)");
     const size_t lds = os_contract_lds(pl->K, pl->KX, pl->NQ) * 8;
     static std::atomic<uint64_t> attr_set{0};
     if ((rc = lds_attr_once(attr_set, pl->device, reinterpret_cast<const void*>(os_contract_kernel<1>), 160 * 1024))) return rc;
-    if (pl->osc_lds) {
-      OsFields in{};
-      in.A[0] = projq_s;
-      in.A[1] = pl->Ax.d() + 1 * KXD;
-      in.A[2] = pl->Ax.d() + 3 * KXD;
-      in.rho[0] = pl->rho_t.d();
-      in.rho[1] = pl->rho.d() + 1 * KRD;
-      in.rho[2] = pl->rho.d() + 3 * KRD;
-      hipLaunchKernelGGL(os_contract_kernel<1>, dim3((unsigned)((Dt + OSC - 1) / OSC)), dim3(256), lds, st, in, projq_s + KXD,
-                         pl->K, pl->KX, pl->KR, pl->NQ, Dt, pl->T.d(), pl->Ginv.d(), pl->G.d(), pl->Gx.d(), pl->gaunt.d(),
-                         pl->wq2.d(), pl->Bq.d(), pl->Bq2.d(), pl->D, (int)pl->tnt, (int)pl->nt, (int)pl->tt0);
-      HIPCHK(hipGetLastError());
-    } else {
-      // q is synthesised here; v and omega at the nodes are those the TEM tail left in the plan (osAt / osAb)
-      const int64_t QD = (int64_t)pl->NQ * Dt;
-      OscFieldsIn fin{};
-      OscPairsIn pin{};
-      fin.A[0] = projq_s;
-      fin.rho[0] = pl->rho_t.d();
-      const int other[2] = {1, 3};                   // v, omega among the TEM run's four fields
+    OsFields in{};
+    in.A[0] = projq_s;
+    in.A[1] = pl->Ax.d() + 1 * KXD;
+    in.A[2] = pl->Ax.d() + 3 * KXD;
+    in.rho[0] = pl->rho_t.d();
+    in.rho[1] = pl->rho.d() + 1 * KRD;
+    in.rho[2] = pl->rho.d() + 3 * KRD;
+    hipLaunchKernelGGL(os_contract_kernel<1>, dim3((unsigned)((Dt + OSC - 1) / OSC)), dim3(256), lds, st, in, projq_s + KXD,
+                       pl->K, pl->KX, pl->KR, pl->NQ, Dt, pl->T.d(), pl->Ginv.d(), pl->G.d(), pl->Gx.d(), pl->gaunt.d(),
+                       pl->wq2.d(), Bq, Bq2, pl->D, (int)pl->tnt, (int)pl->nt, (int)pl->tt0);
+    HIPCHK(hipGetLastError());
+  } else {
+    // the q's are synthesised here; v and omega at the nodes are those the TEM tail left in the plan (osAt / osAb)
+    const int64_t QD = (int64_t)pl->NQ * Dt;
+    OscFieldsIn fin{};
+    OscPairsIn pin{};
+    const int other[2] = {1, 3};                   // v, omega among the TEM run's four fields
+    for (int i = 0; i < nq; ++i) {
+      fin.A[i] = projq_s + i * KXD;
+      fin.rho[i] = pl->rho_t.d() + i * KRD;
       for (int k = 0; k < 2; ++k) {
-        pin.At_a[k] = pl->osAtq.d(); pin.ab_a[k] = pl->osAbq.d();
-        pin.At_b[k] = pl->osAt.d() + other[k] * QD; pin.ab_b[k] = pl->osAb.d() + other[k] * QD;
-        pin.P[k] = projq_s + KXD + (int64_t)k * pl->K * Dt;
+        const int p = 2 * i + k;
+        pin.At_a[p] = pl->osAtq.d() + i * QD; pin.ab_a[p] = pl->osAbq.d() + i * QD;
+        pin.At_b[p] = pl->osAt.d() + other[k] * QD; pin.ab_b[p] = pl->osAb.d() + other[k] * QD;
+        pin.P[p] = projq_s + nq * KXD + (int64_t)p * KDt;
       }
-      if ((rc = launch_osc(pl, fin, 1, 1, pl->Bq.d(), pl->osAtq.d(), pl->osAbq.d(), pin, 2, pl->Bq2.d(), Dt, st))) return rc;
     }
+    if ((rc = launch_osc(pl, fin, nq, nq, Bq, pl->osAtq.d(), pl->osAbq.d(), pin, 2 * nq, Bq2, Dt, st))) return rc;
   }
-  // coefficients Ct = (C_q, C_v, C_w) and qb -> tz[0], as the other tracer stage 2 forms leave them
+  // per tracer: coefficients Ct = (C_q, C_v, C_w) and qb -> tz[0], as the other tracer stage 2 forms leave them
+  // (Ct / tz describe the LAST tracer afterwards: temx_tracer_eddy materialises that one)
   const size_t slab = (size_t)pl->K4 * Dt * 8;
-  if ((rc = launch_solve(pl, pl->Bq.d(), 1, Dt, pl->Ct.d(), pl->tz.d(), st))) return rc;
-  HIPCHK(hipMemcpyAsync((char*)pl->Ct.p + slab, (char*)pl->C4.p + slab, slab, hipMemcpyDeviceToDevice, st));
-  HIPCHK(hipMemcpyAsync((char*)pl->Ct.p + 2 * slab, (char*)pl->C4.p + 3 * slab, slab, hipMemcpyDeviceToDevice, st));
-  return tracer_stage3_impl(pl, pl->Bq2.d(), tres, tzon, st);
+  for (int i = 0; i < nq; ++i) {
+    if ((rc = launch_solve(pl, Bq + i * KDt, 1, Dt, pl->Ct.d(), pl->tz.d(), st))) return rc;
+    HIPCHK(hipMemcpyAsync((char*)pl->Ct.p + slab, (char*)pl->C4.p + slab, slab, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync((char*)pl->Ct.p + 2 * slab, (char*)pl->C4.p + 3 * slab, slab, hipMemcpyDeviceToDevice, st));
+    if ((rc = tracer_stage3_impl(pl, Bq2 + 2 * i * KDt, tres[i], tzon ? tzon[i] : nullptr, st))) return rc;
+  }
+  return TEMX_OK;
 }
 
-static int tracer_run_os(temx_plan* pl, const void* q, const void* va, const void* wap, int dtype, double* tres,
-                         double* tzon, void* stream) {
+static FieldPtrs<4> tracer_fields(int nq, const void* const* q, const void* va, const void* wap) {
+  return nq == 2 ? four(q[0], q[1], va, wap) : four(q[0], va, wap, nullptr);
+}
+
+static int tracer_run_os(temx_plan* pl, int nq, const void* const* q, const void* va, const void* wap, int dtype,
+                         double* const* tres, double* const* tzon, void* stream) {
   hipStream_t st = S_(stream);
   int rc;
-  if ((rc = tracer_os_ws(pl))) return rc;
-  const FieldPtrs<4> fp = four(q, va, wap, nullptr);
-  double* Asq = pl->Axq.d() + (int64_t)(pl->KX + 2 * pl->K) * pl->D;
-  if ((rc = tracer_os_prepass(pl, fp, dtype, Asq, st))) return rc;
-  if ((rc = tracer_os_sweep(pl, fp, dtype, Asq, 1, pl->Axq.d(), st))) return rc;
-  return tracer_os_tail(pl, pl->Axq.d(), tres, tzon, st);
+  if ((rc = tracer_os_ws(pl, nq))) return rc;
+  const FieldPtrs<4> fp = tracer_fields(nq, q, va, wap);
+  double* Asq = pl->Axq.d() + (int64_t)nq * (pl->KX + 2 * pl->K) * pl->D;
+  if ((rc = tracer_os_prepass(pl, nq, fp, dtype, Asq, st))) return rc;
+  if ((rc = tracer_os_sweep(pl, nq, fp, dtype, Asq, 1, pl->Axq.d(), st))) return rc;
+  return tracer_os_tail(pl, nq, pl->Axq.d(), tres, tzon, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2027,7 +2053,7 @@ void temx_plan_destroy(temx_plan* pl) {
   pl->ypblk.release();
   for (DevBuf* b : {&pl->T, &pl->Qp, &pl->GinvA, &pl->G2, &pl->xo, &pl->xc, &pl->ycx, &pl->ycx_s, &pl->crow_s, &pl->side_crow[0][0], &pl->side_crow[0][1], &pl->side_crow[1][0], &pl->side_crow[1][1],
                     &pl->side_gfirst[0][0], &pl->side_gfirst[0][1], &pl->side_gfirst[1][0], &pl->side_gfirst[1][1], &pl->rho,
-                    &pl->rho0, &pl->gaunt, &pl->wq2, &pl->Axq, &pl->rho_t, &pl->Gx, &pl->Gsinv, &pl->Ax, &pl->Axs, &pl->oscblk, &pl->osAt, &pl->osAb, &pl->osAtq, &pl->osAbq})
+                    &pl->rho0, &pl->gaunt, &pl->wq2, &pl->Axq, &pl->rho_t, &pl->Gx, &pl->Gsinv, &pl->Ax, &pl->Axs, &pl->oscblk, &pl->osAt, &pl->osAb, &pl->osAtq, &pl->osAbq, &pl->Bqp})
     b->release();
   for (auto& kv : pl->csplits_s) kv.second.release();
   for (auto& kv : pl->csplits) kv.second.release();
@@ -3090,35 +3116,47 @@ int temx_tem_os_tail(temx_plan* pl, const double* proj_slice, int64_t t0, int64_
   return os_tail(pl, proj_slice, t0, nts, results, zonal, S_(stream));
 }
 
-int temx_tracer_os_prepass(temx_plan* pl, const void* q, const void* va, const void* wap, int dtype, double* Asq, void* stream) {
-  int rc = os_ready(pl);
-  if (rc) return rc;
-  if (!q || !va || !wap || !Asq) return fail(TEMX_EINVAL, "null argument");
+static int tracers_args(const temx_plan* pl, int nq, const void* const* q_host, const void* va, const void* wap, int dtype) {
+  if (nq != 1 && nq != 2) return fail(TEMX_EINVAL, "nq = %d: one or two tracers per sweep", nq);
+  if (!q_host || !q_host[0] || (nq == 2 && !q_host[1]) || !va || !wap) return fail(TEMX_EINVAL, "null argument");
   if (dtype != TEMX_F64 && dtype != TEMX_F32) return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
-  HIPCHK(hipSetDevice(pl->device));
-  return tracer_os_prepass(pl, four(q, va, wap, nullptr), dtype, Asq, S_(stream));
+  if (nq == 2 && (pl->os_tile || pl->osc_lds))
+    return fail(TEMX_EUNSUPPORTED, "two tracers per sweep: not with TEMX_OPT_OS_MAP = tile / TEMX_OPT_OS_CONTRACT = lds");
+  return TEMX_OK;
 }
 
-int temx_tracer_os_sweep(temx_plan* pl, const void* q, const void* va, const void* wap, int dtype, const double* Asq,
-                         int nslices, double* projq, void* stream) {
+int temx_tracers_os_prepass(temx_plan* pl, int nq, const void* const* q_host, const void* va, const void* wap, int dtype,
+                            double* Asq, void* stream) {
   int rc = os_ready(pl);
   if (rc) return rc;
-  if (!q || !va || !wap || !Asq || !projq) return fail(TEMX_EINVAL, "null argument");
-  if (dtype != TEMX_F64 && dtype != TEMX_F32) return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
+  if ((rc = tracers_args(pl, nq, q_host, va, wap, dtype))) return rc;
+  if (!Asq) return fail(TEMX_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(pl->device));
+  return tracer_os_prepass(pl, nq, tracer_fields(nq, q_host, va, wap), dtype, Asq, S_(stream));
+}
+
+int temx_tracers_os_sweep(temx_plan* pl, int nq, const void* const* q_host, const void* va, const void* wap, int dtype,
+                          const double* Asq, int nslices, double* projq, void* stream) {
+  int rc = os_ready(pl);
+  if (rc) return rc;
+  if ((rc = tracers_args(pl, nq, q_host, va, wap, dtype))) return rc;
+  if (!Asq || !projq) return fail(TEMX_EINVAL, "null argument");
   if ((rc = slices_ok(pl, nslices))) return rc;
   HIPCHK(hipSetDevice(pl->device));
-  return tracer_os_sweep(pl, four(q, va, wap, nullptr), dtype, Asq, nslices, projq, S_(stream));
+  return tracer_os_sweep(pl, nq, tracer_fields(nq, q_host, va, wap), dtype, Asq, nslices, projq, S_(stream));
 }
 
-int temx_tracer_os_tail(temx_plan* pl, const double* projq_slice, double* tres, double* tzon, void* stream) {
+int temx_tracers_os_tail(temx_plan* pl, int nq, const double* projq_slice, double* const* tres_host, double* const* tzon_host,
+                         void* stream) {
   int rc = os_ready(pl);
   if (rc) return rc;
-  if (!projq_slice || !tres) return fail(TEMX_EINVAL, "null argument");
+  if (nq != 1 && nq != 2) return fail(TEMX_EINVAL, "nq = %d: one or two tracers per sweep", nq);
+  if (!projq_slice || !tres_host || !tres_host[0] || (nq == 2 && !tres_host[1])) return fail(TEMX_EINVAL, "null argument");
   if (!pl->os_valid || !pl->c4_valid)
-    return fail(TEMX_ESTATE, "the tracer's tail needs the state of a temx_tem_os_tail on the same snapshots");
+    return fail(TEMX_ESTATE, "the tracers' tail needs the state of a temx_tem_os_tail on the same snapshots");
   HIPCHK(hipSetDevice(pl->device));
-  if ((rc = tracer_os_ws(pl))) return rc;
-  return tracer_os_tail(pl, projq_slice, tres, tzon, S_(stream));
+  if ((rc = tracer_os_ws(pl, nq))) return rc;
+  return tracer_os_tail(pl, nq, projq_slice, tres_host, tzon_host, S_(stream));
 }
 
 // stages 2b + 3 on a time slice, from raw sums of any form of the sweeps: B4s [4][K][nlev][nts], B3s [3][K][nlev][nts]
@@ -3420,7 +3458,10 @@ int temx_tracer_run(temx_plan* pl, const void* q, const void* va, const void* wa
     if (!q || !va || !wap || !tres) return fail(TEMX_EINVAL, "null argument");
     if (dtype != TEMX_F64 && dtype != TEMX_F32) return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
     HIPCHK(hipSetDevice(pl->device));
-    return tracer_run_os(pl, q, va, wap, dtype, tres, tzon, stream);
+    const void* qs[1] = {q};
+    double* tr[1] = {tres};
+    double* tz[1] = {tzon};
+    return tracer_run_os(pl, 1, qs, va, wap, dtype, tr, tz, stream);
   }
   if ((rc = tracer_ws(pl))) return rc;
   // The one-pass form reads (q, v, omega) once instead of q + (q, v, omega), but its sweep shares a SIMD
@@ -3434,6 +3475,31 @@ int temx_tracer_run(temx_plan* pl, const void* q, const void* va, const void* wa
   if ((rc = temx_tracer_stage1(pl, q, dtype, pl->Bq.d(), stream))) return rc;
   if ((rc = temx_tracer_stage2(pl, q, va, wap, dtype, pl->Bq.d(), pl->Bq2.d(), stream))) return rc;
   return temx_tracer_stage3(pl, pl->Bq2.d(), tres, tzon, stream);
+}
+
+// nq tracers of one TEM run (tem_diagnostics.py:281-301 takes a list): after a single-sweep TEM run they are swept
+// in PAIRS -- (q1, q2, v, omega) read once: the traffic of the TEM sweep for two tracers instead of 3/4 of it for each
+// -- and a last odd one alone; on any other path one temx_tracer_run after the other.
+int temx_tracers_run(temx_plan* pl, int nq, const void* const* q_host, const void* va, const void* wap, int dtype,
+                     double* const* tres_host, double* const* tzon_host, void* stream) {
+  int rc = tem_ready(pl);
+  if (rc) return rc;
+  if (nq < 1 || !q_host || !tres_host) return fail(TEMX_EINVAL, "bad argument");
+  for (int i = 0; i < nq; ++i)
+    if (!q_host[i] || !tres_host[i]) return fail(TEMX_EINVAL, "null argument");
+  const bool os = pl->os_valid && pl->c4_valid && tail_is_whole(pl) && os_active(pl, dtype) && !pl->os_tile && !pl->osc_lds &&
+                  (dtype == TEMX_F64 || dtype == TEMX_F32);
+  int i = 0;
+  if (os) {
+    if (!va || !wap) return fail(TEMX_EINVAL, "null argument");
+    if ((rc = os_ready(pl))) return rc;
+    HIPCHK(hipSetDevice(pl->device));
+    for (; i + 1 < nq; i += 2)
+      if ((rc = tracer_run_os(pl, 2, q_host + i, va, wap, dtype, tres_host + i, tzon_host ? tzon_host + i : nullptr, stream))) return rc;
+  }
+  for (; i < nq; ++i)
+    if ((rc = temx_tracer_run(pl, q_host[i], va, wap, dtype, tres_host[i], tzon_host ? tzon_host[i] : nullptr, stream))) return rc;
+  return TEMX_OK;
 }
 
 int temx_tracer_eddy(temx_plan* pl, const void* q, const void* va, const void* wap, int dtype,

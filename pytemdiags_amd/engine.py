@@ -271,27 +271,58 @@ class Plan:
                                         _ptr(zon) if zon is not None else None, self._stream()))
         return res, zon
 
-    def tracer_os_prepass(self, q, va, wap, out=None):
-        (qq, v, w), dt = self._three(q, va, wap)
-        Asq = out if out is not None else torch.empty((self.KR, self.D), dtype=torch.float64, device=self.device)
-        check(self.lib.temx_tracer_os_prepass(self._h, _ptr(qq), _ptr(v), _ptr(w), dt, _ptr(Asq), self._stream()))
+    # tracers in the single-sweep form: one or two per sweep (two share one read of v and omega)
+    def _tracers(self, qs, va, wap):
+        if isinstance(qs, torch.Tensor):
+            qs = [qs]
+        if len(qs) not in (1, 2):
+            raise ValueError("one or two tracers per sweep")
+        fs, dt = self._three(qs[0], va, wap)
+        qq = [fs[0]] + [self._field(x, self.D) for x in qs[1:]]
+        if len({x.dtype for x in qq}) != 1:
+            raise TypeError("the tracers must share the dtype of va, wap")
+        ptrs = (C.c_void_p * len(qq))(*[x.data_ptr() for x in qq])
+        return qq, ptrs, fs[1], fs[2], dt
+
+    def tracers_os_prepass(self, qs, va, wap, out=None):
+        qq, ptrs, v, w, dt = self._tracers(qs, va, wap)
+        Asq = out if out is not None else torch.empty((len(qq), self.KR, self.D), dtype=torch.float64, device=self.device)
+        check(self.lib.temx_tracers_os_prepass(self._h, len(qq), ptrs, _ptr(v), _ptr(w), dt, _ptr(Asq), self._stream()))
         return Asq
 
-    def tracer_os_sweep(self, q, va, wap, Asq, nslices=1, out=None):
-        (qq, v, w), dt = self._three(q, va, wap)
-        projq = out if out is not None else self._sliced(self.KX + 2 * self.K, nslices)
-        check(self.lib.temx_tracer_os_sweep(self._h, _ptr(qq), _ptr(v), _ptr(w), dt, _ptr(Asq.contiguous()), int(nslices),
-                                            _ptr(projq), self._stream()))
+    def tracers_os_sweep(self, qs, va, wap, Asq, nslices=1, out=None):
+        qq, ptrs, v, w, dt = self._tracers(qs, va, wap)
+        projq = out if out is not None else self._sliced(len(qq) * (self.KX + 2 * self.K), nslices)
+        check(self.lib.temx_tracers_os_sweep(self._h, len(qq), ptrs, _ptr(v), _ptr(w), dt, _ptr(Asq.contiguous()), int(nslices),
+                                             _ptr(projq), self._stream()))
         return projq
 
-    def tracer_os_tail(self, projq_slice, nts, want_zonal=False):
-        tres = torch.empty((len(_lib.TRACER_RESULT_NAMES), self.M, self.nlev, nts), dtype=torch.float64, device=self.device)
-        tzon = None
-        if want_zonal:
-            tzon = torch.empty((len(_lib.TRACER_ZONAL_NAMES), self.M, self.nlev, nts), dtype=torch.float64, device=self.device)
-        check(self.lib.temx_tracer_os_tail(self._h, _ptr(projq_slice), _ptr(tres), _ptr(tzon) if tzon is not None else None,
-                                           self._stream()))
-        return tres, tzon
+    def _tracer_outs(self, nq, nts, want_zonal):
+        tres = [torch.empty((len(_lib.TRACER_RESULT_NAMES), self.M, self.nlev, nts), dtype=torch.float64, device=self.device)
+                for _ in range(nq)]
+        tzon = [torch.empty((len(_lib.TRACER_ZONAL_NAMES), self.M, self.nlev, nts), dtype=torch.float64, device=self.device)
+                for _ in range(nq)] if want_zonal else None
+        pr = (C.c_void_p * nq)(*[t.data_ptr() for t in tres])
+        pz = (C.c_void_p * nq)(*[t.data_ptr() for t in tzon]) if want_zonal else None
+        return tres, tzon, pr, pz
+
+    def tracers_os_tail(self, nq, projq_slice, nts, want_zonal=False):
+        """-> [(tres, tzon)] per tracer, for the snapshots of the latest ``tem_os_tail``."""
+        tres, tzon, pr, pz = self._tracer_outs(nq, nts, want_zonal)
+        check(self.lib.temx_tracers_os_tail(self._h, int(nq), _ptr(projq_slice), pr, pz, self._stream()))
+        return [(tres[i], tzon[i] if tzon else None) for i in range(nq)]
+
+    def tracers_run(self, qs, va, wap, want_zonal=False):
+        """All tracers of a TEM run (temx_tracers_run): in pairs on the single-sweep path.  -> [(tres, tzon)]."""
+        qs = list(qs)
+        fs, dt = self._three(qs[0], va, wap)
+        qq = [fs[0]] + [self._field(x, self.D) for x in qs[1:]]
+        if len({x.dtype for x in qq}) != 1:
+            raise TypeError("the tracers must share the dtype of va, wap")
+        ptrs = (C.c_void_p * len(qq))(*[x.data_ptr() for x in qq])
+        tres, tzon, pr, pz = self._tracer_outs(len(qq), self.nt, want_zonal)
+        check(self.lib.temx_tracers_run(self._h, len(qq), ptrs, _ptr(fs[1]), _ptr(fs[2]), dt, pr, pz, self._stream()))
+        return [(tres[i], tzon[i] if tzon else None) for i in range(len(qq))]
 
     def time_slices(self, B, nslices):
         """Rows of [nlev][nt] columns -> the reduce-scatter layout [nslices][chunk] (temx_time_slices)."""

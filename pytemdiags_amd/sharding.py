@@ -204,12 +204,7 @@ class NcolShardedTEM:
         [2][K][D] sums of q'v', q'w')."""
         be = self.backend
         if self._sliced:
-            Asq = be.tracer_os_prepass(q, va, wap, out=self._buffer("Asq", (be.KR, be.D)))
-            allreduce_sum_(Asq, self.group)
-            projq = be.tracer_os_sweep(q, va, wap, Asq, nslices=self.world, out=self._slices("projq", be.KX + 2 * be.K))
-            mine = reduce_scatter_sum(projq, self.group, out=self._buffer("mineq", projq.shape[1:]))
-            t0, t1 = shard_bounds(int(be.nt), self.world, self.rank)
-            return be.tracer_os_tail(mine, t1 - t0, want_zonal)
+            return self.run_tracers([q], va, wap, want_zonal)[0]
         if getattr(be, "tracer_one_pass", False):      # (q, v, omega) read once, see include/temx.h
             Bq = be.tracer_stage1_sums(q, va, wap)
             allreduce_sum_(Bq, self.group)
@@ -220,6 +215,29 @@ class NcolShardedTEM:
             Bq2 = be.tracer_stage2(q, va, wap, Bq)
         allreduce_sum_(Bq2, self.group)
         return be.tracer_stage3(Bq2, want_zonal)
+
+
+    def _run_tracers_sliced(self, qs, va, wap, want_zonal):
+        be = self.backend
+        nq = len(qs)
+        Asq = be.tracers_os_prepass(qs, va, wap, out=self._buffer("Asq%d" % nq, (nq, be.KR, be.D)))
+        allreduce_sum_(Asq, self.group)
+        projq = be.tracers_os_sweep(qs, va, wap, Asq, nslices=self.world,
+                                    out=self._slices("projq%d" % nq, nq * (be.KX + 2 * be.K)))
+        mine = reduce_scatter_sum(projq, self.group, out=self._buffer("mineq%d" % nq, projq.shape[1:]))
+        t0, t1 = shard_bounds(int(be.nt), self.world, self.rank)
+        return be.tracers_os_tail(nq, mine, t1 - t0, want_zonal)
+
+    def run_tracers(self, qs, va, wap, want_zonal=False):
+        """All tracers of the run (tem_diagnostics.py:281-301 takes a list) -> [(tres, tzon)].  Time-sliced tail: two
+        tracers per sweep ((q1, q2, v, omega) read once), one all-reduce and one reduce-scatter per pair."""
+        qs = list(qs)
+        if not self._sliced:
+            return [self.run_tracer(q, va, wap, want_zonal) for q in qs]
+        out = []
+        for i in range(0, len(qs), 2):
+            out += self._run_tracers_sliced(qs[i:i + 2], va, wap, want_zonal)
+        return out
 
 
 class TimeShardedTEM:

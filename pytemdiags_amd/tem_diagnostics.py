@@ -70,9 +70,10 @@ class TEMDiagnostics:
         # ---- the whole numeric pipeline: one engine call (tem_diagnostics.py:252-259) ----
         plan = self.ZM._plan
         plan.set_tem(self.NLEV, self.NT, self._p_np, float(self.p0))
-        # (the first tracer, when there is one, shares the sweep of the fields: temx_tem_tracer_run)
+        # (class-sum forms: the first tracer, when there is one, shares the sweep of the fields, temx_tem_tracer_run;
+        #  single sweep: the tracers follow the TEM run in pairs, temx_tracers_run)
         fused = None
-        if self.ntrac:
+        if self.ntrac and not plan.single_sweep:
             self._res, self._zon, *fused = plan.tem_tracer_run(*self._dev_fields, self._dev_q[0], want_zonal=True)
         else:
             self._res, self._zon = plan.tem_run(*self._dev_fields, want_zonal=True)
@@ -85,14 +86,21 @@ class TEMDiagnostics:
         # ---- tracers (tem_diagnostics.py:532-538, 560-570, 602-611): one engine call each ----
         self._tres, self._tzon, self._teddy = [], [], [None] * self.ntrac
         self._last_tracer = None
-        for i in range(self.ntrac):
-            if i == 0 and fused is not None:
-                tres, tzon = fused
-            else:
-                tres, tzon = plan.tracer_run(self._dev_q[i], self._dev_fields[1], self._dev_fields[3], want_zonal=True)
-            self._tres.append(tres)
-            self._tzon.append(tzon)
-            self._last_tracer = i
+        if self.ntrac and plan.single_sweep:
+            # the list of tracers in one engine call: two per sweep, (q1, q2, v, omega) read once
+            for tres, tzon in plan.tracers_run(self._dev_q, self._dev_fields[1], self._dev_fields[3], want_zonal=True):
+                self._tres.append(tres)
+                self._tzon.append(tzon)
+            self._last_tracer = self.ntrac - 1
+        else:
+            for i in range(self.ntrac):
+                if i == 0 and fused is not None:
+                    tres, tzon = fused
+                else:
+                    tres, tzon = plan.tracer_run(self._dev_q[i], self._dev_fields[1], self._dev_fields[3], want_zonal=True)
+                self._tres.append(tres)
+                self._tzon.append(tzon)
+                self._last_tracer = i
         if self.ntrac and plan.status():
             raise RuntimeError("Variable has nans! Spectral zonal averager cannot handle nans; "
                                "please replace or remove them")

@@ -18,7 +18,7 @@ int main(void) {
       (const void*)temx_kernel_timing, (const void*)temx_kernel_timing_read,
       (const void*)temx_plan_configure, (const void*)temx_plan_option, (const void*)temx_plan_set_os_matrices,
       (const void*)temx_tem_os_prepass, (const void*)temx_tem_os_sweep, (const void*)temx_tem_os_tail,
-      (const void*)temx_tracer_os_prepass, (const void*)temx_tracer_os_sweep, (const void*)temx_tracer_os_tail,
+      (const void*)temx_tracers_os_prepass, (const void*)temx_tracers_os_sweep, (const void*)temx_tracers_os_tail, (const void*)temx_tracers_run,
       (const void*)temx_tem_tail_from_sums, (const void*)temx_time_slices};
   unsigned n = (unsigned)(sizeof(syms) / sizeof(syms[0])), i, ok = 0;
   for (i = 0; i < n; ++i) ok += syms[i] != 0;

@@ -1,5 +1,5 @@
 """The single sweep in three steps and its time-sliced tail (include/temx.h: temx_tem_os_prepass / _sweep / _tail,
-temx_tracer_os_*, temx_tem_tail_from_sums, temx_time_slices) -- the form an ncol-sharded job runs: the zonal sums are
+temx_tracers_os_*, temx_tem_tail_from_sums, temx_time_slices) -- the form an ncol-sharded job runs: the zonal sums are
 linear in the rows (sph_zonal_mean.py:251) and everything after them acts along latitude and pressure only
 (tem_diagnostics.py:574-797), so the ranks exchange the sums by a reduce-scatter over time and each finishes its own
 snapshots.  Here the collectives are written out as explicit sums on one GPU; tests/test_gpu_multiproc.py runs the
@@ -69,8 +69,8 @@ def test_three_steps_and_time_slices_equal_the_whole_run(ne, nlev, nt, dtype, L,
     projW = plan.tem_os_sweep(*d, As, nslices=W)
     ntmax = -(-nt // W)
     assert projW.shape == (W, plan.os_rows * nlev * ntmax)
-    Asq = plan.tracer_os_prepass(dq, d[1], d[3])
-    projq = plan.tracer_os_sweep(dq, d[1], d[3], Asq, nslices=W)
+    Asq = plan.tracers_os_prepass([dq], d[1], d[3])
+    projq = plan.tracers_os_sweep([dq], d[1], d[3], Asq, nslices=W)
     for w in range(W):
         t0, t1 = sharding.shard_bounds(nt, W, w)
         mine = projW[w][: plan.os_rows * nlev * (t1 - t0)].reshape(plan.os_rows, nlev, t1 - t0)
@@ -80,7 +80,7 @@ def test_three_steps_and_time_slices_equal_the_whole_run(ne, nlev, nt, dtype, L,
         assert torch.equal(rw, res[..., t0:t1]) and torch.equal(zw, zon[..., t0:t1])
         with pytest.raises(_lib.TemxError):                          # the plan now describes a slice: whole-run stage 3 refuses
             plan.tem_stage3(torch.zeros((3, plan.K, plan.D), dtype=torch.float64, device="cuda:0"))
-        tw, tzw = plan.tracer_os_tail(projq[w], t1 - t0, want_zonal=True)
+        (tw, tzw), = plan.tracers_os_tail(1, projq[w], t1 - t0, want_zonal=True)
         assert torch.equal(tw, tres[..., t0:t1]) and torch.equal(tzw, tzon[..., t0:t1])
     # back to the whole run: the staged class-sum entry points work again and agree
     B4 = plan.tem_stage1(*d)
@@ -133,7 +133,7 @@ def test_ncol_shards_with_time_sliced_tail_emulated_on_one_gpu(ne, nlev, nt, W):
     locq = [_dev(q[m]) for m in shards]
     As = sum(p.tem_os_prepass(*x) for p, x in zip(plans, loc))
     proj = sum(p.tem_os_sweep(*x, As, nslices=W) for p, x in zip(plans, loc))
-    Asq = sum(p.tracer_os_prepass(xq, x[1], x[3]) for p, x, xq in zip(plans, loc, locq))
+    Asq = sum(p.tracers_os_prepass([xq], x[1], x[3]) for p, x, xq in zip(plans, loc, locq))
     projq = None
     outs, touts = [], []
     for w, p in enumerate(plans):
@@ -141,10 +141,10 @@ def test_ncol_shards_with_time_sliced_tail_emulated_on_one_gpu(ne, nlev, nt, W):
         r, _ = p.tem_os_tail(proj[w], t0, t1 - t0)
         outs.append(r)
     # (the tracer's sweep needs its plan's references of v and omega: those of the latest tem_os_sweep, still in place)
-    projq = sum(p.tracer_os_sweep(xq, x[1], x[3], Asq, nslices=W) for p, x, xq in zip(plans, loc, locq))
+    projq = sum(p.tracers_os_sweep([xq], x[1], x[3], Asq, nslices=W) for p, x, xq in zip(plans, loc, locq))
     for w, p in enumerate(plans):
         t0, t1 = sharding.shard_bounds(nt, W, w)
-        t, _ = p.tracer_os_tail(projq[w], t1 - t0)
+        (t, _), = p.tracers_os_tail(1, projq[w], t1 - t0)
         touts.append(t)
     got, tgot = torch.cat(outs, dim=-1), torch.cat(touts, dim=-1)
     for p in plans:
@@ -236,3 +236,88 @@ def test_contraction_on_the_matrix_cores_equals_the_lds_form(ne, nlev, nt, dtype
     for a, b, names in zip(out["mfma"], out["lds"], (_lib.RESULT_NAMES, _lib.ZONAL_NAMES, _lib.TRACER_RESULT_NAMES)):
         for i, n in enumerate(names):
             assert _relerr(a[i], b[i]) <= tol, n
+
+
+@pytest.mark.parametrize("ne,nlev,nt,dtype,L,ntr", [
+    (12, 10, 7, np.float64, 50, 2),
+    (12, 16, 5, np.float32, 50, 3),     # fp32 inputs (two waves per SIMD); an odd tracer left over
+    (10, 9, 8, np.float64, 28, 5),      # TBS = 4
+])
+def test_two_tracers_per_sweep(ne, nlev, nt, dtype, L, ntr):
+    """The reference takes a LIST of tracers (tem_diagnostics.py:281-301, 532-538, 560-570).  After a single-sweep TEM
+    run they are swept in pairs -- (q1, q2, v, omega) read once -- and must give what one tracer at a time gives
+    (temx_tracer_run, itself held to the oracle and the reference's goldens elsewhere); also sliced in time."""
+    from pytemdiags_amd import _lib, engine, sharding, synth
+    _skip_if_forced_elsewhere()
+    if os.environ.get("TEMX_OS_MAP") == "tile" or os.environ.get("TEMX_OS_CONTRACT") == "lds":
+        pytest.skip("two tracers per sweep need the row-map sweep and the contraction on the matrix cores")
+    lat, lon, plev, f, q, lat_zm = _case(ne, nlev, nt, dtype)
+    qs = [_dev(synth.analytic_tracer(lat, lon, plev, nt, which=i).astype(dtype)) for i in range(ntr)]
+    d = [_dev(x) for x in f]
+    plan = engine.Plan(lat, lat_zm, L, form="single-sweep")
+    plan.set_tem(nlev, nt, plev * 100)
+    res, _ = plan.tem_run(*d)
+    single = [plan.tracer_run(x, d[1], d[3], want_zonal=True) for x in qs]
+    paired = plan.tracers_run(qs, d[1], d[3], want_zonal=True)
+    assert len(paired) == ntr and not plan.status()
+    tol = 1e-12 if dtype == np.float64 else 1e-6
+    for i in range(ntr):
+        for a, b, names in zip(paired[i], single[i], (_lib.TRACER_RESULT_NAMES, _lib.TRACER_ZONAL_NAMES)):
+            for k, n in enumerate(names):
+                assert _relerr(a[k], b[k]) <= tol, (i, n)
+    again = plan.tracers_run(qs, d[1], d[3], want_zonal=True)
+    assert all(torch.equal(x[0], y[0]) for x, y in zip(paired, again))      # fixed-order reductions
+    # the pair in three steps, its tail on time slices
+    W = 2
+    Asq = plan.tracers_os_prepass(qs[:2], d[1], d[3])
+    assert Asq.shape == (2, plan.KR, plan.D)
+    projq = plan.tracers_os_sweep(qs[:2], d[1], d[3], Asq, nslices=W)
+    As = plan.tem_os_prepass(*d)
+    proj = plan.tem_os_sweep(*d, As, nslices=W)
+    for w in range(W):
+        t0, t1 = sharding.shard_bounds(nt, W, w)
+        plan.tem_os_tail(proj[w], t0, t1 - t0)
+        outs = plan.tracers_os_tail(2, projq[w], t1 - t0, want_zonal=True)
+        for i in range(2):
+            assert torch.equal(outs[i][0], paired[i][0][..., t0:t1]) and torch.equal(outs[i][1], paired[i][1][..., t0:t1])
+    assert not plan.status()
+    plan.close()
+
+
+def test_reference_two_tracer_golden_through_the_pair_sweep():
+    """The reference's own run with a LIST of two tracers (tests/golden/tracer_ne4_10x2_f64.npz, made by
+    tools/make_goldens.py from the unmodified reference) through the pair sweep.  The golden has D = 10 x 2 columns,
+    fewer than the one-pass forms take; every step of the pipeline is independent per snapshot
+    (tem_diagnostics.py:510-797 never mix times), so the two snapshots are repeated four times and every repetition
+    must reproduce the reference's numbers."""
+    from conftest import GOLDEN, fieldnorm_err
+    from pytemdiags_amd import _lib, engine
+    _skip_if_forced_elsewhere()
+    if os.environ.get("TEMX_OS_MAP") == "tile" or os.environ.get("TEMX_OS_CONTRACT") == "lds":
+        pytest.skip("two tracers per sweep need the row-map sweep and the contraction on the matrix cores")
+    g = np.load(os.path.join(GOLDEN, "tracer_ne4_10x2_f64.npz"), allow_pickle=True)
+    assert int(g["ntrac"]) == 2
+    rep = 4
+    tile = lambda x: _dev(np.tile(np.asarray(x), (1, 1, rep)))                # noqa: E731  [ncol][plev][time x rep]
+    d = [tile(g[k]) for k in ("ua", "va", "ta", "wap")]
+    qs = [tile(g["q0"]), tile(g["q1"])]
+    nlev, nt = g["ua"].shape[1], g["ua"].shape[2] * rep
+    lat_zm = (np.arange(-90, 91, 1.0)[1:] + np.arange(-90, 91, 1.0)[:-1]) / 2
+    plan = engine.Plan(g["lat"], lat_zm, 50, form="single-sweep")
+    plan.set_tem(nlev, nt, np.asarray(g["plev"]) * 100)
+    assert plan.single_sweep
+    res, _ = plan.tem_run(*d)
+    out = plan.tracers_run(qs, d[1], d[3], want_zonal=True)
+    assert not plan.status()
+    res = res.cpu().numpy()
+    for r in range(rep):
+        sl = slice(2 * r, 2 * r + 2)
+        for i, n in enumerate(_lib.RESULT_NAMES):
+            assert fieldnorm_err(res[i][..., sl], g["res_" + n]) <= 1e-10, (r, n)
+        for qi in range(2):
+            tres, tzon = out[qi][0].cpu().numpy(), out[qi][1].cpu().numpy()
+            for k, n in enumerate(_lib.TRACER_RESULT_NAMES):
+                assert fieldnorm_err(tres[k][..., sl], g["q%d_res_%s" % (qi, n)]) <= 1e-10, (r, qi, n)
+            for k, n in enumerate(_lib.TRACER_ZONAL_NAMES):
+                assert fieldnorm_err(tzon[k][..., sl], np.asarray(g["q%d_%s" % (qi, n)], np.float64)) <= 1e-10, (r, qi, n)
+    plan.close()

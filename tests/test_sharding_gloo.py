@@ -216,34 +216,38 @@ class SingleSweepOracleBackend(OracleBackend):
         o = orc.TEMOracle.from_zonal_means(self.zon, self.plev)
         return torch.from_numpy(np.stack([getattr(o, n)() for n in orc.RESULTS])), None
 
-    def tracer_os_prepass(self, q, va, wap, out=None):
-        qf = np.asarray(q).reshape(q.shape[0], -1)
-        return torch.from_numpy(self._prepass([qf])[0])
+    def tracers_os_prepass(self, qs, va, wap, out=None):
+        return torch.from_numpy(np.stack(self._prepass([np.asarray(q).reshape(q.shape[0], -1) for q in qs])))
 
-    def tracer_os_sweep(self, q, va, wap, Asq, nslices=1, out=None):
-        qf = np.asarray(q).reshape(q.shape[0], -1)
-        self.rho_q = np.linalg.solve(self.Gs, Asq.numpy())
-        qs = qf - self.Y0[:, :self.KR] @ self.rho_q
+    def tracers_os_sweep(self, qs, va, wap, Asq, nslices=1, out=None):
+        qf = [np.asarray(q).reshape(q.shape[0], -1) for q in qs]
+        self.rho_q = [np.linalg.solve(self.Gs, a) for a in Asq.numpy()]
+        qsft = [x - self.Y0[:, :self.KR] @ r for x, r in zip(qf, self.rho_q)]
         vs, ws = self._kept_vw                                                # (the same v, omega as the TEM run)
-        return self._slices(np.concatenate([self.Yx.T @ qs, self.Y0.T @ (qs * vs), self.Y0.T @ (qs * ws)]), nslices)
+        prods = [self.Y0.T @ (x * y) for x in qsft for y in (vs, ws)]          # q1 v, q1 omega, q2 v, q2 omega
+        return self._slices(np.concatenate([self.Yx.T @ x for x in qsft] + prods), nslices)
 
-    def tracer_os_tail(self, mine, nts, want_zonal=False):
+    def tracers_os_tail(self, nq, mine, nts, want_zonal=False):
         t0, nts0, A, al = self._tail
         assert nts == nts0
-        rows = self.KX + 2 * self.K
+        rows = nq * (self.KX + 2 * self.K)
         m = mine.numpy().reshape(-1)[: rows * self.nlev * nts].reshape(rows, self.nlev * nts)
-        Aq, P = m[:self.KX], [m[self.KX + k * self.K: self.KX + (k + 1) * self.K] for k in range(2)]
-        alq = self.Ginv @ Aq[:self.K]
         tr = (self.nlev, nts)
-        cq = alq + np.pad(self.rho_q[:, self._cols(t0, nts)], ((0, self.K - self.KR), (0, 0)))
-        zq = {"qb": (self.Y0p @ cq).reshape((-1,) + tr)}
-        for n, f, p in zip(("qpvpb", "qpwappb"), (1, 3), P):
-            zq[n] = (self.Y0p @ (self.Ginv @ self._lin(Aq, alq, A[f], al[f], p))).reshape((-1,) + tr)
-        o = orc.TEMOracle.from_zonal_means(self.zon, self.plev)
-        o.q = [np.empty(0)]
-        o.qb, o.qpvpb, o.qpwappb = [zq["qb"]], [zq["qpvpb"]], [zq["qpwappb"]]
-        o._derivatives()
-        return torch.from_numpy(np.stack([getattr(o, n)(0) for n in orc.TRACER_RESULTS])), None
+        outs = []
+        for i in range(nq):
+            Aq = m[i * self.KX:(i + 1) * self.KX]
+            P = [m[nq * self.KX + (2 * i + k) * self.K: nq * self.KX + (2 * i + k + 1) * self.K] for k in range(2)]
+            alq = self.Ginv @ Aq[:self.K]
+            cq = alq + np.pad(self.rho_q[i][:, self._cols(t0, nts)], ((0, self.K - self.KR), (0, 0)))
+            zq = {"qb": (self.Y0p @ cq).reshape((-1,) + tr)}
+            for n, fld, p in zip(("qpvpb", "qpwappb"), (1, 3), P):
+                zq[n] = (self.Y0p @ (self.Ginv @ self._lin(Aq, alq, A[fld], al[fld], p))).reshape((-1,) + tr)
+            o = orc.TEMOracle.from_zonal_means(self.zon, self.plev)
+            o.q = [np.empty(0)]
+            o.qb, o.qpvpb, o.qpwappb = [zq["qb"]], [zq["qpvpb"]], [zq["qpwappb"]]
+            o._derivatives()
+            outs.append((torch.from_numpy(np.stack([getattr(o, n)(0) for n in orc.TRACER_RESULTS])), None))
+        return outs
 
 
 _LON = synth.cubed_sphere_gll(NE)[1]
@@ -276,6 +280,10 @@ def _worker(rank, world, port, mode, ret):
             res, _ = runner.run(*[x[i0:i1] for x in f])
             q = synth.analytic_tracer(lat, _LON, plev, NT)
             tres, _ = runner.run_tracer(q[i0:i1], f[1][i0:i1], f[3][i0:i1])
+            if mode == "ncol-sliced":      # the list form: a pair in one sweep must repeat the single run
+                q2 = synth.analytic_tracer(lat, _LON, plev, NT, which=1)
+                both = runner.run_tracers([q[i0:i1], q2[i0:i1]], f[1][i0:i1], f[3][i0:i1])
+                assert len(both) == 2 and float((both[0][0] - tres).abs().max()) <= 1e-12 * float(tres.abs().max())
             if mode == "ncol-sliced":      # every rank holds its own snapshots: ragged 3 + 2 of NT = 5
                 t0, t1 = runner.my_snapshots()
                 assert (t0, t1) == sharding.shard_bounds(NT, world, rank) and res.shape[-1] == t1 - t0
