@@ -751,6 +751,7 @@ sweep_osr_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
   uint64_t fbase[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) fbase[f] = reinterpret_cast<uint64_t>(fp.p[f]);
+  { double sth_ready = sth; asm volatile("" : "+v"(sth_ready)); }     // (see sweep_os2_kernel: no tracked load may stay pending into the loop)
 
   double ax[NFX][NBX];
 #pragma unroll
@@ -1020,6 +1021,9 @@ sweep_osr_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
 // The exchange, the barriers, the deferred projection (two chunks here: a side of a cubed-sphere class is two
 // batches) and the hand-issued loads are those of sweep_osr_kernel.
 // ------------------------------------------------------------------------------------------------
+#ifndef TEMX_OS2_STAGGER
+#define TEMX_OS2_STAGGER 0
+#endif
 template <typename T, int TBS, int TBX, int NBR, int PD, int KIND = 0>
 __global__ void __launch_bounds__(512, 1)
 sweep_os2_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restrict__ ycx,
@@ -1092,6 +1096,11 @@ sweep_os2_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
   uint64_t fbase[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) fbase[f] = reinterpret_cast<uint64_t>(fp.p[f]);
+  // The column scale is the one load of this kernel the compiler tracks; used first inside the loop, its wait would
+  // be placed THERE -- as `s_waitcnt vmcnt(0)`, since the pass cannot see the hand-issued loads behind it: a drain of
+  // the ring once per class-group (found by tools/isa_check.py in round 4; ne120 x 72 x 30 fp32: 6.6 -> see DESIGN 5d).
+  // A use here settles it before the first row load is issued.
+  { double sth_ready = sth; asm volatile("" : "+v"(sth_ready)); }
 
   double ax[NFX][TBX];
 #pragma unroll
@@ -1160,7 +1169,12 @@ sweep_os2_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
       rn = crow[(int64_t)(b + PD) * 4 + (wave & 3)];
       issue(std::integral_constant<int, (P + PD - 1) % PD>{}, r1);
     }
-    if (left > 0) {                           // the loads of the next batch are in flight meanwhile
+    // The two waves of a SIMD (one per side of the same classes) reach every barrier together, so left alone they
+    // also run the same phase at the same time: both on the matrix pipe, then both on the VALU, then both waiting.
+    // TEMX_OS2_STAGGER: the southern wave runs its projection chunk AFTER the accumulation instead of before it, so
+    // that one wave's MFMAs meet the other's VALU work (the pipes are separate).
+    const bool early = !(TEMX_OS2_STAGGER) || side == 0;
+    if (early && left > 0) {                  // the loads of the next batch are in flight meanwhile
       pending_chunk(std::integral_constant<int, POS>{});
       --left;
     }
@@ -1187,6 +1201,10 @@ sweep_os2_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
 #pragma unroll
       for (int k = 0; k < NP; ++k) q[k] += (w * dx[KD::pa(k)]) * dx[KD::pb(k)];
       cnt += w;
+    }
+    if (!early && left > 0) {
+      pending_chunk(std::integral_constant<int, POS>{});
+      --left;
     }
     if (fl & (CLS_LAST << 1)) {
       if (left > 0)                           // (a side shorter than NCH steps: what is left of the previous projection)
@@ -1552,18 +1570,26 @@ sweep_opr_kernel(FieldPtrs<4> fp, int64_t D, int K, const double* __restrict__ y
 // reference coefficients of the single-sweep form: rho[f][l][d] = sum_m Gsinv[l][m] As[f][m][d], l, m < KR
 // (As: projections of a subsample of class-groups onto the first KR harmonics, the first rows of each field of a
 // [nf][KX][D] array; summed over the ranks when the job is ncol-sharded)
-__global__ void os_ref_solve_kernel(const double* __restrict__ As, int KX /* rows per field in As */, int KR, int64_t D,
-                                    const double* __restrict__ Gsinv, double* __restrict__ rho) {
-  const int64_t d = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256)
+os_ref_solve_kernel(const double* __restrict__ As, int KX /* rows per field in As */, int KR, int64_t D,
+                    const double* __restrict__ Gsinv, double* __restrict__ rho) {
+  // one thread per (l, d): 16 x the threads of a thread per column, which was latency bound at 22 us (36 workgroups)
+  __shared__ double sg[16 * 16];
   const int f = blockIdx.y;
-  if (d >= D) return;
-  double a[16];
-  for (int m = 0; m < KR; ++m) a[m] = As[((int64_t)f * KX + m) * D + d];
-  for (int l = 0; l < KR; ++l) {
-    double v = 0.0;
-    for (int m = 0; m < KR; ++m) v += Gsinv[l * KR + m] * a[m];
-    rho[((int64_t)f * KR + l) * D + d] = v;
+  for (int i = threadIdx.x; i < KR * KR; i += blockDim.x) sg[i] = Gsinv[i];
+  __syncthreads();
+  const int64_t d = blockIdx.x * (int64_t)(blockDim.x / 16) + (threadIdx.x & 15);
+  const int l = threadIdx.x >> 4;
+  if (d >= D || l >= KR) return;
+  const double* a = As + (int64_t)f * KX * D + d;
+  double v0 = 0.0, v1 = 0.0;
+  int m = 0;
+  for (; m + 2 <= KR; m += 2) {
+    v0 += sg[l * KR + m] * a[(int64_t)m * D];
+    v1 += sg[l * KR + m + 1] * a[(int64_t)(m + 1) * D];
   }
+  if (m < KR) v0 += sg[l * KR + m] * a[(int64_t)m * D];
+  rho[((int64_t)f * KR + l) * D + d] = v0 + v1;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1819,7 +1819,7 @@ static int os_sweep(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, const doub
   const int64_t D = pl->D;
   const int64_t KD4 = (int64_t)4 * pl->KX * D, KD3 = (int64_t)3 * pl->K * D;
   pl->op_valid = pl->c4_valid = pl->tq_valid = pl->os_valid = false;
-  hipLaunchKernelGGL(os_ref_solve_kernel, dim3((unsigned)((D + 255) / 256), 4), dim3(256), 0, st, As, pl->KR, pl->KR, D,
+  hipLaunchKernelGGL(os_ref_solve_kernel, dim3((unsigned)((D + 15) / 16), 4), dim3(256), 0, st, As, pl->KR, pl->KR, D,
                      pl->Gsinv.d(), pl->rho.d());
   HIPCHK(hipGetLastError());
   TimedLaunch tl{};
@@ -1935,7 +1935,7 @@ static int tracer_os_sweep(temx_plan* pl, int nq, const FieldPtrs<4>& fp, int dt
   if ((rc = tracer_os_ws(pl, nq))) return rc;
   pl->tq_valid = false;
   // references: (rho_q, rho_v, rho_omega) / (rho_q1, rho_q2, rho_v, rho_omega), v and omega as the TEM run fitted them
-  hipLaunchKernelGGL(os_ref_solve_kernel, dim3((unsigned)((D + 255) / 256), nq), dim3(256), 0, st, Asq, pl->KR, pl->KR, D,
+  hipLaunchKernelGGL(os_ref_solve_kernel, dim3((unsigned)((D + 15) / 16), nq), dim3(256), 0, st, Asq, pl->KR, pl->KR, D,
                      pl->Gsinv.d(), pl->rho_t.d());
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(pl->rho_t.d() + nq * KRD, pl->rho.d() + 1 * KRD, (size_t)KRD * 8, hipMemcpyDeviceToDevice, st));         // v

@@ -6,7 +6,7 @@ import numpy as np, torch
 from pytemdiags_amd import engine, synth
 
 ne, nlev, nt = (int(x) for x in sys.argv[1].lower().replace("ne", "").split("x"))
-lat, lon = synth.cubed_sphere_gll(ne)
+lat, lon = synth.cubed_sphere_gll(ne, mirror=False)
 plev = synth.pressure_levels(nlev)
 lat_zm = (np.arange(-90, 91, 1.0)[1:] + np.arange(-90, 91, 1.0)[:-1]) / 2
 plan = engine.Plan(lat, lat_zm, 50)

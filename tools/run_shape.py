@@ -12,7 +12,7 @@ ne, nlev, nt = (int(x) for x in sys.argv[1].lower().replace("ne", "").split("x")
 dt = torch.float32 if len(sys.argv) > 2 and sys.argv[2] == "f32" else torch.float64
 form = sys.argv[3] if len(sys.argv) > 3 else "auto"
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
-lat, lon = synth.cubed_sphere_gll(ne)
+lat, lon = synth.cubed_sphere_gll(ne, mirror=False)
 plev = synth.pressure_levels(nlev)
 lat_zm = (np.arange(-90, 91, 1.0)[1:] + np.arange(-90, 91, 1.0)[:-1]) / 2
 plan = engine.Plan(lat, lat_zm, 50, form=None if form == "auto" else form)

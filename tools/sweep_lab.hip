@@ -534,7 +534,7 @@ int run(int64_t N, int64_t D, int reps, const char* only) {
     }
     const double bytes = 4.0 * N * D * sizeof(T);
     printf("%-70s nsplit %3d  avg %7.3f ms  min %7.3f ms  %5.2f TB/s  (%.3f of 8)", v.name.c_str(), v.nsplit,
-           sum / reps, best, bytes / (sum / reps) / 1e9, bytes / (sum / reps) / 1e9 / 8000.0);
+           sum / reps, best, bytes / (sum / reps) / 1e9, bytes / (sum / reps) / 1e9 / 8.0);
     if (compared) printf("  dB %.1e dcsum %.1e\n", eB, eC);
     else printf(have_ref ? "  (not compared with the library kernel)\n" : "  (the reference)\n");
     fflush(stdout);
