@@ -13,7 +13,9 @@ N > 1   : one rank per GPU over RCCL, launched by `python -m torch.distributed.r
           ... bench.py --gpus N`; invoked directly (`python bench.py --gpus N`) it starts that
           launcher itself as a child process, before anything touches the GPU, and returns its
           exit code.  The metric is BASELINE.json configs[3]: ONE ne120x72x30 job, its columns sharded
-          over the ranks in whole latitude classes, the zonal sums all-reduced over RCCL/xGMI (strong
+          over the ranks in whole latitude classes, the sums of the single sweep exchanged over RCCL/xGMI by a
+          reduce-scatter over time, every rank finishing its own snapshots (all-reduces + replicated tail on plans
+          that cannot run the single sweep; strong
           scaling: total work fixed).  Reported beside it under "other_workloads": configs[2],
           ne30 x 72 x 730 snapshots time-sharded (91/92 per rank at N = 8, no collective; strong
           scaling), and the weak-scaling run (every rank its own ne120x72x30 block, no collective).
