@@ -623,14 +623,14 @@ sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restr
 #pragma unroll
       for (int t = 0; t < NBX; ++t) {
         const int l = symx_harm<TBX>(t, g);
-        if (l < KX) px[(((int64_t)split * NFX + f) * KX + l) * D + d] = ax[f][t];
+        if (l < (pp != nullptr ? KX : K4)) px[(((int64_t)split * NFX + f) * KX + l) * D + d] = ax[f][t];   // (pre-pass, pp == NULL: only the K4 rows of the reference fit)
       }
 #pragma unroll
     for (int k = 0; k < NP; ++k)
 #pragma unroll
       for (int t = 0; t < 2 * TBS; ++t) {
         const int l = sym_harm<TBS>(t, g);
-        if (l < K) pp[(((int64_t)split * NP + k) * K + l) * D + d] = apl[(k * 2 * TBS + t) * 64];
+        if (pp != nullptr && l < K) pp[(((int64_t)split * NP + k) * K + l) * D + d] = apl[(k * 2 * TBS + t) * 64];
       }
   }
 }
@@ -996,14 +996,14 @@ sweep_osr_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
 #pragma unroll
       for (int t = 0; t < NBX; ++t) {
         const int l = symx_harm<TBX>(t, g);
-        if (l < KX) px[(((int64_t)split * NFX + f) * KX + l) * D + d] = ax[f][t];
+        if (l < (pp != nullptr ? KX : K4)) px[(((int64_t)split * NFX + f) * KX + l) * D + d] = ax[f][t];   // (pre-pass, pp == NULL: only the K4 rows of the reference fit)
       }
 #pragma unroll
     for (int k = 0; k < NP; ++k)
 #pragma unroll
       for (int t = 0; t < 2 * TBS; ++t) {
         const int l = sym_harm<TBS>(t, g);
-        if (l < K) pp[(((int64_t)split * NP + k) * K + l) * D + d] = k < NPR ? apr[k < NPR ? k : 0][t] : apl[((k < NPR ? 0 : k - NPR) * 2 * TBS + t) * 64];
+        if (pp != nullptr && l < K) pp[(((int64_t)split * NP + k) * K + l) * D + d] = k < NPR ? apr[k < NPR ? k : 0][t] : apl[((k < NPR ? 0 : k - NPR) * 2 * TBS + t) * 64];
       }
   }
 }
@@ -1023,6 +1023,9 @@ sweep_osr_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
 // ------------------------------------------------------------------------------------------------
 #ifndef TEMX_OS2_STAGGER
 #define TEMX_OS2_STAGGER 0
+#endif
+#ifndef TEMX_OS2_ACC32
+#define TEMX_OS2_ACC32 1
 #endif
 template <typename T, int TBS, int TBX, int NBR, int PD, int KIND = 0>
 __global__ void __launch_bounds__(512, 1)
@@ -1107,11 +1110,17 @@ sweep_os2_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
   for (int f = 0; f < NFX; ++f)
 #pragma unroll
     for (int t = 0; t < TBX; ++t) ax[f][t] = 0.0;
-  double s[NF], q[NP], x0[NF], cnt = 0.0;
+  // fp32 inputs: the sums of a class side about its first member, S~ = sum (x - x0) and q~ = sum (a - a0)(b - b0), are
+  // accumulated in fp32 (TEMX_OS2_ACC32).  The differences are eddy-sized and a side has 8 members on a cubed sphere:
+  // the rounding of these sums is ~1e-7 of the EDDY amplitude, four orders below the 2e-5 the fp32 path is held to
+  // (the reference's own fp32-input run differs from its fp64 run by 5e-6), and everything from the side
+  // means on is fp64 as before.  It takes the conversions and the quarter-rate fp64 VALU work out of the inner loop.
+  using AT = typename std::conditional<(sizeof(T) == 4 && TEMX_OS2_ACC32), float, double>::type;
+  AT s[NF], q[NP], x0[NF], cnt = 0;
 #pragma unroll
-  for (int f = 0; f < NF; ++f) s[f] = x0[f] = 0.0;
+  for (int f = 0; f < NF; ++f) s[f] = x0[f] = 0;
 #pragma unroll
-  for (int k = 0; k < NP; ++k) q[k] = 0.0;
+  for (int k = 0; k < NP; ++k) q[k] = 0;
   const uint32_t rowbytes = (uint32_t)D * (uint32_t)sizeof(T);   // host guarantees D < 2^28
 
   T xb[PD][MB][NF];
@@ -1188,14 +1197,14 @@ sweep_os2_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
     const int fl = er[P][0] >> 27;            // has-padding, (south), first, last: of the batch on this side
     if (fl & (CLS_FIRST << 1)) {
 #pragma unroll
-      for (int f = 0; f < NF; ++f) x0[f] = (double)xb[P][0][f];
+      for (int f = 0; f < NF; ++f) x0[f] = (AT)xb[P][0][f];
     }
 #pragma unroll
     for (int j = 0; j < MB; ++j) {
-      const double w = er[P][j] < 0 ? 0.0 : 1.0;   // (a padding entry: the whole row of this wave)
-      double dx[NF];
+      const AT w = er[P][j] < 0 ? (AT)0 : (AT)1;   // (a padding entry: the whole row of this wave)
+      AT dx[NF];
 #pragma unroll
-      for (int f = 0; f < NF; ++f) dx[f] = (double)xb[P][j][f] - x0[f];
+      for (int f = 0; f < NF; ++f) dx[f] = (AT)xb[P][j][f] - x0[f];
 #pragma unroll
       for (int f = 0; f < NF; ++f) s[f] += w * dx[f];
 #pragma unroll
@@ -1212,19 +1221,21 @@ sweep_os2_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
           if (((decltype(cc)::value - POS - 1) & (NCH - 1)) < left) pending_chunk(cc);
         });
       // ---- reading role: mean (theta = T x the column scale) and central co-moments of my class side
-      const double rcn = cnt > 0.0 ? temx_rcp_count(cnt) : 0.0;
+      const double cntd = (double)cnt;
+      const double rcn = cntd > 0.0 ? temx_rcp_count(cntd) : 0.0;
       double val[NV];
 #pragma unroll
-      for (int f = 0; f < NF; ++f) val[f] = (s[f] * rcn + x0[f]) * (f == KD::TF ? sth : 1.0);
+      for (int f = 0; f < NF; ++f) val[f] = ((double)s[f] * rcn + (double)x0[f]) * (f == KD::TF ? sth : 1.0);
 #pragma unroll
-      for (int k = 0; k < NP; ++k) val[NF + k] = (q[k] - s[KD::pa(k)] * s[KD::pb(k)] * rcn) * (k == KD::TP ? sth : 1.0);
+      for (int k = 0; k < NP; ++k)
+        val[NF + k] = ((double)q[k] - (double)s[KD::pa(k)] * (double)s[KD::pb(k)] * rcn) * (k == KD::TP ? sth : 1.0);
       // every wave is done with the exchange area of the previous group (LDS reads retired, loads stay in flight)
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       ycur ^= 1;
       double* yw = ybase + ycur * YE;
 #pragma unroll
       for (int v = 0; v < NV; ++v) exw[v * 512] = val[v];
-      if (lane == 0) cn[wave] = cnt;
+      if (lane == 0) cn[wave] = cntd;
       if (tid < YE) yw[tid] = ys;
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       ++grp;
@@ -1275,10 +1286,10 @@ sweep_os2_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
       yprev = yw + par * (TBX * 16);
       left = NCH;
 #pragma unroll
-      for (int f = 0; f < NF; ++f) s[f] = 0.0;
+      for (int f = 0; f < NF; ++f) s[f] = 0;
 #pragma unroll
-      for (int k = 0; k < NP; ++k) q[k] = 0.0;
-      cnt = 0.0;
+      for (int k = 0; k < NP; ++k) q[k] = 0;
+      cnt = 0;
     }
   };
 
@@ -1312,14 +1323,14 @@ sweep_os2_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __rest
 #pragma unroll
       for (int t = 0; t < TBX; ++t) {
         const int l = 2 * (4 * t + g) + par;  // block t of parity par, row g (symx_harm<TBX>(par * TBX + t, g))
-        if (l < KX) px[(((int64_t)split * NFX + f) * KX + l) * D + d] = ax[f][t];
+        if (l < (pp != nullptr ? KX : K4)) px[(((int64_t)split * NFX + f) * KX + l) * D + d] = ax[f][t];   // (pre-pass, pp == NULL: only the K4 rows of the reference fit)
       }
 #pragma unroll
     for (int k = 0; k < NP; ++k)
 #pragma unroll
       for (int t = 0; t < TBS; ++t) {
         const int l = 2 * (4 * t + g) + par;
-        if (l < K) pp[(((int64_t)split * NP + k) * K + l) * D + d] = k < NPR ? apr[k < NPR ? k : 0][t] : apl[((k < NPR ? 0 : k - NPR) * TBS + t) * 64];
+        if (pp != nullptr && l < K) pp[(((int64_t)split * NP + k) * K + l) * D + d] = k < NPR ? apr[k < NPR ? k : 0][t] : apl[((k < NPR ? 0 : k - NPR) * TBS + t) * 64];
       }
   }
 }

@@ -1680,7 +1680,9 @@ static int launch_sweep_os_t(temx_plan* pl, const FieldPtrs<4>& fp, bool sub, co
   // loads of 1 row x 64 columns (sweep_osr_kernel, the default) or of 4 rows x 16 columns (TEMX_OS_MAP=tile, A/B)
   const bool tile_map = pl->os_tile;
   double* px = partial;
-  double* pp = partial + (int64_t)sp.nsplit * KD::NFX * pl->KX * pl->D;
+  // (the reference pre-pass needs the first KR rows of px only: pp == NULL tells the kernels to store nothing else --
+  //  146 x 8 B per lane and workgroup otherwise, 150 MB at ne120 x 72 x 30 for a sweep that reads 240 MB)
+  double* pp = sub ? nullptr : partial + (int64_t)sp.nsplit * KD::NFX * pl->KX * pl->D;
 #define TEMX_LOS(TBSv, TBXv)                                                                                        \
   do {                                                                                                              \
     if constexpr (KIND == 3) {                                                                                      \

@@ -777,10 +777,14 @@ def test_row_map_sweeps_equal_tile_map_sweeps(monkeypatch, ne, nlev, nt, dtype):
         assert not plan.status()
         out[form] = [x.clone() for x in (res, zon, tres, B4, B3, sres)]
         plan.close()
+    # fp32 inputs: the row-map single sweep (sweep_os2_kernel) accumulates the sums of a class side about its first
+    # member in fp32, the tile-map kernels in fp64: they agree to ~1e-7 of the eddy amplitude, not to
+    # rounding of fp64 -- both far inside the 2e-5 the fp32 path is held to against the oracle.
+    tol = 1e-11 if dtype == np.float64 else 5e-6
     for a, b, what in zip(out["row"], out["tile"], ("results", "zonal", "tracer results", "B4", "B3", "staged results")):
         for i in range(a.shape[0]):
             scale = float(b[i].abs().max())
-            assert float((a[i] - b[i]).abs().max()) <= 1e-11 * scale, (what, i)
+            assert float((a[i] - b[i]).abs().max()) <= tol * scale, (what, i)
 
 
 @pytest.mark.parametrize("dtype,single", [(np.float64, True), (np.float32, True), (np.float64, False)])

@@ -81,6 +81,36 @@ def vregs(text):
     return out
 
 
+def pk_used(op, rest):
+    """Registers a packed-fp32 VALU instruction reads or writes: each source is a register pair of which op_sel /
+    op_sel_hi pick one register per half (op_sel 0 -> the low register feeds the low result, op_sel_hi 1 -> the high
+    register feeds the high result); a pair named with op_sel_hi 0 and op_sel 0 is only read in its low register."""
+    ops = [o.strip() for o in rest.split(",")]
+    mods = " ".join(o for o in ops if ":" in o and "[" in o and not o.startswith(("v[", "-v[", "|v[")))
+    plain = [o for o in rest.replace(mods, "").split(",") if o.strip()]
+
+    def sel(name, n, dflt):
+        m = re.search(name + r":\[([01,]+)\]", rest)
+        v = [int(x) for x in m.group(1).split(",")] if m else []
+        return (v + [dflt] * n)[:n]
+    toks = []
+    for o in plain:
+        t = o.strip().split()[0] if o.strip() else ""
+        toks.append(t)
+    toks = [t for t in toks if t and not t.startswith(("op_sel", "neg_"))]
+    used = vregs(toks[0]) if toks else set()                  # destination pair: both written
+    srcs = toks[1:]
+    lo, hi = sel("op_sel", len(srcs), 0), sel("op_sel_hi", len(srcs), 1)
+    for i, t in enumerate(srcs):
+        r = sorted(vregs(t))
+        if len(r) == 2:
+            used.add(r[1] if lo[i] else r[0])
+            used.add(r[1] if hi[i] else r[0])
+        else:
+            used |= set(r)
+    return used
+
+
 def check(name, body, verbose=False):
     hand = re.compile(r"^\s*global_load_dword(x2)?\s+(\S+),\s*v\d+,\s*s\[\d+:\d+\].*\bnt\b")
     best = None
@@ -142,7 +172,7 @@ def check(name, body, verbose=False):
                         fifo.pop(0)
                 continue
             if trip == 1 and (op.startswith(("v_", "ds_")) or op.startswith("s_") is False):
-                used = vregs(rest)
+                used = pk_used(op, rest) if op.startswith("v_pk_") and "f32" in op else vregs(rest)
                 for r_ in fifo:
                     hit = r_ & used
                     if hit:
