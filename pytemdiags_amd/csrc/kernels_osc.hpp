@@ -39,6 +39,10 @@ struct OscMats {
   const double* Gx;      // [NBK][NBX]
 };
 
+// (Round 4 also built the variant with the matrix of each product staged in LDS by a two-wave workgroup -- an LDS read
+// broadcasts, while streamed from L2 every lane of the four 16-lane groups fetches the same 16 doubles of a block:
+// 512 bytes of L1 bandwidth per MFMA.  It measured 0.21 ms against 0.088: 144-153 KB of LDS leave one workgroup of
+// two waves per CU, and its seven stage-and-barrier phases wait for L2 with nothing else to run.  Not kept.)
 #ifndef TEMX_OSC_PF
 #define TEMX_OSC_PF 4
 #endif
@@ -116,6 +120,16 @@ osc_fields_kernel(OscFieldsIn in, OscMats m, int K, int KX, int KR, int NQ, int6
     va[kb * 64] = row < KX ? v : 0.0;
   }
   auto zero = [](int) { return 0.0; };
+  // gridDim.z == 2: the synthesis of the field itself, At = Yq A (676 of a wave's 1742 MFMAs at L = 50), does not
+  // depend on alpha and runs in waves of its own (blockIdx.z == 1): twice the waves, a shorter critical path
+  if (gridDim.z == 2 && blockIdx.z == 1) {
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h)
+      osc_mm<NBK, NBX>(m.Yq, h * NBK, va, aoff, zero, [&](int mb, double v) {
+        if (dvalid && 4 * mb + g < NQ) At[((int64_t)f * NQ + 4 * mb + g) * Dt + d] = v;
+      });
+    return;
+  }
   // (rows >= K of A ride along in the last block of A[:K]: the matrices are zero there)
   // ---- coefficients of the zonal mean of the shifted field: alpha = T (G2inv (T^T A[:K]))  -> vt0
   osc_mm<NBK, NBK>(m.Tt, 0, va, aoff, zero, [&](int mb, double v) { vt0[mb * 64] = v; });
@@ -142,9 +156,10 @@ osc_fields_kernel(OscFieldsIn in, OscMats m, int K, int KX, int KR, int NQ, int6
     osc_mm<NBK, NBK>(m.YqK, h * NBK, vt0, aoff, zero, [&](int mb, double v) {
       if (dvalid && 4 * mb + g < NQ) ab[((int64_t)f * NQ + 4 * mb + g) * Dt + d] = v;
     });
-    osc_mm<NBK, NBX>(m.Yq, h * NBK, va, aoff, zero, [&](int mb, double v) {
-      if (dvalid && 4 * mb + g < NQ) At[((int64_t)f * NQ + 4 * mb + g) * Dt + d] = v;
-    });
+    if (gridDim.z == 1)
+      osc_mm<NBK, NBX>(m.Yq, h * NBK, va, aoff, zero, [&](int mb, double v) {
+        if (dvalid && 4 * mb + g < NQ) At[((int64_t)f * NQ + 4 * mb + g) * Dt + d] = v;
+      });
   }
 }
 

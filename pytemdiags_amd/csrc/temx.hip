@@ -1780,7 +1780,7 @@ template <int NBK>
 static int launch_osc_t(temx_plan* pl, const OscFieldsIn& fin, int nf, int nout, double* Bf, double* At, double* ab,
                         const OscPairsIn& pin, int np, double* Bp, int64_t Dt, hipStream_t st) {
   const unsigned gx = (unsigned)((Dt + 15) / 16);       // one wave = one workgroup = one d-tile of one field / pair
-  hipLaunchKernelGGL((osc_fields_kernel<NBK>), dim3(gx, nf), dim3(64), (size_t)osc_fields_lds(NBK) * 8, st, fin, pl->osc, pl->K,
+  hipLaunchKernelGGL((osc_fields_kernel<NBK>), dim3(gx, nf, 2), dim3(64), (size_t)osc_fields_lds(NBK) * 8, st, fin, pl->osc, pl->K,
                      pl->KX, pl->KR, pl->NQ, Dt, nout, Bf, At, ab, pl->D, (int)pl->tnt, (int)pl->nt, (int)pl->tt0);
   HIPCHK(hipGetLastError());
   hipLaunchKernelGGL((osc_pairs_kernel<NBK>), dim3(gx, np), dim3(64), (size_t)osc_pairs_lds(NBK) * 8, st, pin, pl->osc, pl->wq2.d(),
