@@ -879,3 +879,63 @@ def test_latitude_noise_of_real_grids_keeps_the_class_sweeps():
     for i, n in enumerate(_lib.RESULT_NAMES):
         assert fieldnorm_err(res[i].cpu().numpy(), np.asarray(getattr(ref, n)(), np.float64)) <= 2e-5, n
     plan.close()
+
+
+def test_sharded_job_on_a_grid_that_is_not_symmetric_mixed_sweep_forms():
+    """temx_plan_finalize used to decide Q = Y0 R^-1 against Y0 from which sweeps the RANK's own block
+    takes; on a job whose grid is not equatorially symmetric, a rank with latitude classes kept Y0 and a rank without
+    them took Q, and the all-reduced sums mixed two bases.  With a Gram matrix from outside the choice now depends on
+    that (global) matrix alone.  Here: rank A owns a symmetric band of a cubed sphere (class sweeps), rank B the columns
+    poleward of it with their latitudes jittered by up to 1e-3 degrees (no classes, no mirror pairs: generic sweeps);
+    the job's grid, their union, covers the sphere (cond(G) = 2.3) but is not symmetric: the odd entries of its Gram
+    matrix are 2e-5 of the diagonal, not rounding noise.  The replicated flow with explicit sums against the oracle
+    and against the unsharded run on the same grid."""
+    from pytemdiags_amd import _lib, engine, synth
+    import os
+    if any(os.environ.get(k) == "1" for k in ("TEMX_NO_SYM", "TEMX_NO_CLS")):
+        pytest.skip("needs ranks that take different sweeps")
+    lat0, lon0 = synth.cubed_sphere_gll(10)
+    rng = np.random.default_rng(12)
+    a = np.flatnonzero(np.abs(lat0) <= 35.0)
+    b = np.flatnonzero(np.abs(lat0) > 35.0)
+    lat = lat0.copy()
+    lat[b] += rng.uniform(-1e-3, 1e-3, b.size)
+    keep = np.concatenate([a, b])
+    lat, lon = lat[keep], lon0[keep]
+    parts = [np.arange(a.size), a.size + np.arange(b.size)]
+    nlev, nt = 8, 3
+    plev = synth.pressure_levels(nlev)
+    lat_zm = (np.arange(-90, 91, 2.0)[1:] + np.arange(-90, 91, 2.0)[:-1]) / 2
+    L = 50
+    fh = synth.analytic_fields(lat, lon, plev, nt, seed=4)
+    f = [torch.as_tensor(x, device="cuda:0") for x in fh]
+    from oracle import tem_oracle as orc
+    o = orc.TEMOracle(*fh, lat, plev, zm_dlat=2, L=L, mode="factorised")
+    full = engine.Plan(lat, lat_zm, L)
+    full.set_tem(nlev, nt, plev * 100)
+    ref, _ = full.tem_run(*f)
+    assert not full.status()
+    for i, n in enumerate(_lib.RESULT_NAMES):
+        assert fieldnorm_err(ref[i].cpu().numpy(), getattr(o, n)()) <= 1e-10, n
+    plans = [engine.Plan(lat[p], lat_zm, L, defer_finalize=True) for p in parts]
+    assert plans[0].sweep_mode == 2 and plans[1].sweep_mode == 0         # class sweeps / generic sweeps
+    G = sum(pl.matrix(_lib.MAT_GRAM) for pl in plans).cpu().numpy()
+    assert np.max(np.abs(G[0::2, 1::2])) > 1e-6 * np.max(np.abs(np.diag(G)))     # not a checkerboard: the job is not symmetric
+    for pl in plans:
+        pl.finalize(G)
+    G2 = sum(pl.matrix(_lib.MAT_GRAM2) for pl in plans).cpu().numpy()
+    loc = []
+    for pl, p in zip(plans, parts):
+        pl.refine(G2)
+        pl.set_tem(nlev, nt, plev * 100)
+        idx = torch.as_tensor(p, device="cuda:0")
+        loc.append([x[idx].contiguous() for x in f])
+    B4 = sum(pl.tem_stage1(*l) for pl, l in zip(plans, loc))
+    B3 = sum(pl.tem_stage2_from_sums(B4) if pl.one_pass else pl.tem_stage2(*l, B4) for pl, l in zip(plans, loc))
+    for pl in plans:
+        res, _ = pl.tem_stage3(B3)
+        for i, n in enumerate(_lib.RESULT_NAMES):
+            assert fieldnorm_err(res[i].cpu().numpy(), ref[i].cpu().numpy()) <= 1e-10, n
+    assert not any(pl.status() for pl in plans)
+    for pl in plans + [full]:
+        pl.close()

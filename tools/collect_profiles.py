@@ -50,7 +50,7 @@ def write_table(kt_dir, out, title):
 
 def pmc(dirname):
     """{kernel: {counter: [values per dispatch]}}"""
-    f = sorted(glob.glob(os.path.join(S, dirname, "**", "*counter_collection.csv"), recursive=True))[-1]
+    f = max(glob.glob(os.path.join(S, dirname, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     d = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         d[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -38,7 +38,7 @@ def clusters(vals, ratio=4.0):
 
 def table(path):
     if os.path.isdir(path):
-        path = sorted(glob.glob(os.path.join(path, "**", "*kernel_trace.csv"), recursive=True))[-1]
+        path = max(glob.glob(os.path.join(path, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
     acc = defaultdict(list)
     text = {}
     with open(path) as fh:

@@ -24,7 +24,7 @@ python tools/graph_probe.py ne30x72x1 > "$O/graph_probe.log" 2>&1
 echo "tracer / graph probes done"
 cd /tmp
 export TMPDIR=/tmp
-A="--steps 5 --warmup 1 --no-cpu-baseline --also="
+A="--steps 20 --warmup 3 --no-cpu-baseline --also="
 rocprofv3 --kernel-trace --output-format csv -d "$O/kt_bench" -- python3 "$REPO/bench.py" $A > "$O/prof.log" 2>&1
 echo "kernel trace done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python3 "$REPO/bench.py" $A >> "$O/prof.log" 2>&1
