@@ -537,6 +537,8 @@ def test_fuzz_random_grids_and_shapes(seed, monkeypatch):
     # cond(G) = cond(Y0)^2 = 1e8 (round 2 scaled it from cond(G) = 2e3 up).  The BASELINE grids: cond(G) <= 20.
     cond = np.linalg.cond(ref.ZM.Y0.T @ ref.ZM.Y0)
     tol = (1e-10 if dtype == np.float64 else 2e-5) * max(1.0, cond / 1e8)
+    if __import__("os").environ.get("TEMX_NO_QR") == "1":    # A/B runs on the plain normal equations: round 2's scaling
+        tol = (1e-10 if dtype == np.float64 else 2e-5) * max(1.0, cond / 2e3)
     info = (seed, lat.size, nlev, nt, L, dtype.__name__, plan.sweep_mode, plan.one_pass, "cond %.1e" % cond)
     for i, n in enumerate(_lib.RESULT_NAMES):
         e = fieldnorm_err(res[i].cpu().numpy(), getattr(ref, n)())
