@@ -4,16 +4,18 @@ Two ways the path shards:
 
 * **time sharding** -- the columns of the (N x D) operand are independent, so each rank takes a
   contiguous block of time snapshots with a replicated plan.  No collective on the data path.
-* **ncol sharding** -- rows split in blocks (whole latitude classes per rank, see
-  ``symmetric_ncol_shards``); the only cross-row reduction is the
-  projection ``Y0^T A``, so each rank computes partial sums over its rows and the ranks
-  all-reduce (i) the K x K Gram matrix (and the Gram matrix of the re-orthogonalised basis) once at plan build, (ii) the [4][K][D] sums of
-  (u, v, theta, omega) and (iii) the [3][K][D] sums of the eddy products -- one fused message
-  each.  Every rank then solves the K x K system and evaluates the (tiny) zonal-grid epilogue
-  redundantly.
+* **ncol sharding** -- rows split in blocks (whole latitude classes per rank, see ``symmetric_ncol_shards``).  The
+  zonal sums are linear in the rows (sph_zonal_mean.py:251) and everything after them acts along latitude and
+  pressure only (tem_diagnostics.py:574-797), so the ranks exchange the sums and split the TAIL over time:
+  plans that run the single sweep all-reduce the reference pre-pass sums ([4][16][D]), reduce-scatter the sweep's
+  projections over time, and every rank finishes its own snapshots -- nothing of the tail is replicated, the
+  results stay time-sharded (``gather_time``).  Any other plan: all-reduce of the [4][K][D] sums of (u, v, theta,
+  omega) and of the [3][K][D] sums of the eddy products, every rank solving the K x K system and evaluating the
+  zonal-grid epilogue redundantly.  Once at plan build: the K x K Gram matrix, the Gram matrix of the
+  re-orthogonalised basis, and for the single sweep its two matrices that sum over the rows.
 
 The driver below only sequences stages and collectives; the numerics live behind a *backend*
-with the ``engine.Plan`` stage interface (``matrix``, ``finalize``, ``tem_stage1/2/3``).  On
+with the ``engine.Plan`` stage interface (``matrix``, ``finalize``, ``tem_stage1/2/3``, ``tem_os_prepass/sweep/tail``).  On
 the GPU the backend is ``engine.Plan``; the world_size-2 gloo tests drive the same code with a
 CPU stand-in built on the oracle.
 """
