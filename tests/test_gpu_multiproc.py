@@ -145,7 +145,7 @@ def test_bench_line_at_two_ranks_and_failure_exit_code():
     assert rec["process_group"]["ranks"] == 2 and rec["value"] > 0 and "errors" not in rec
     ow = rec["other_workloads"]
     ts = ow["ne30x72x9:time_sharded"]
-    assert ts["scaling"] == "strong" and ts["shard"] == "time" and ts["snapshots_this_rank"] == 5 and ts["value"] > 0
+    assert ts["scaling"] == "strong" and ts["shard"] == "time" and ts["snapshots_this_rank"] == 4 and ts["value"] > 0      # 9 snapshots in blocks of whole cache lines per row: 4 + 5
     assert ow["ne30x72x8:weak_scaling"]["scaling"] == "weak"
     # a forced failure of the time-sharded leg: the line still comes out, with the error, and the exit code is 4
     env["TEMX_BENCH_FAIL"] = "ne30x72x9:time_sharded"

@@ -341,3 +341,19 @@ def test_world1_is_a_no_op():
     t = torch.ones(3)
     assert sharding.allreduce_sum_(t) is t and float(t.sum()) == 3.0
     assert sharding.gather_time(t) is t
+
+
+def test_shard_bounds_in_multiples():
+    """Time blocks of whole cache lines per row (sharding.aligned_snapshots): every rank but possibly the last gets a
+    multiple, the blocks tile [0, n), sizes differ by at most one multiple."""
+    assert sharding.aligned_snapshots(72, 8) == 2 and sharding.aligned_snapshots(72, 4) == 4
+    assert sharding.aligned_snapshots(128, 4) == 1 and sharding.aligned_snapshots(30, 8) == 8
+    b = [sharding.shard_bounds(730, 8, r, 2) for r in range(8)]
+    assert [hi - lo for lo, hi in b] == [92, 92, 92, 92, 92, 90, 90, 90]
+    for n, w, m in ((730, 8, 2), (731, 8, 2), (30, 8, 4), (7, 8, 2), (100, 3, 8), (64, 4, 16)):
+        b = [sharding.shard_bounds(n, w, r, m) for r in range(w)]
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[r][1] == b[r + 1][0] for r in range(w - 1)), (n, w, m, b)
+        if n // m >= w:
+            assert all((hi - lo) % m == 0 for lo, hi in b[:-1]), (n, w, m, b)
+            assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b[:-1]) <= m, (n, w, m, b)
+    assert [sharding.shard_bounds(5, 2, r) for r in range(2)] == [(0, 3), (3, 5)]      # the default is unchanged
