@@ -15,10 +15,10 @@
 // The first version of this contraction (os_contract_kernel) stages every matrix in LDS and walks them with scalar
 // FMAs, 4 columns per workgroup: 0.23 ms at D = 2160 and growing with D beyond one round of workgroups -- the reason
 // the single sweep stopped at grids with >= 2048 class-groups.  A one-kernel MFMA form was measured in round 3 at
-// 0.20 ms (59 dependent phases of one L2 latency each on 135 workgroups).  Here the vectors of a d-tile live in
-// wave-private LDS in the operand layout, the matrix blocks stream from L2 through a register ring PF steps ahead of
-// the MFMAs that use them (the loops are rolled: written unrolled, the compiler hoisted every block load of a product
-// and spilled), and a workgroup is one wave, so the ~950 waves of the two launches spread over the chip.
+// 0.20 ms (59 dependent phases of one L2 latency each on 135 workgroups).  Here the vectors of a d-tile live in LDS in
+// the operand layout, the matrix blocks stream from L2 through a register ring PF steps ahead of the MFMAs that use
+// them (the loops are rolled: written unrolled, the compiler hoisted every block load of a product and spilled), and
+// the four waves of a workgroup share one d-tile, each computing every fourth output block of a product.
 //
 // Matrices are 4x4 A-operand blocks built on the host (append_blocks): blk[(mb * NKB + kb) * 16 + k * 4 + i] =
 // M[4 mb + i][4 kb + k], zero padded to whole blocks; a lane's element of a block is at g * 4 + (lane & 3), g = lane >> 4.
@@ -48,32 +48,44 @@ struct OscMats {
 #endif
 constexpr int OSC_PF = TEMX_OSC_PF;       // matrix blocks are loaded this many steps ahead of their MFMAs
 
-// MC output blocks mb0 .. mb0 + MC - 1 of  M . x:  acc[mb] = init(mb) + sum_kb blk[mb][kb] . x[kb],  kb < KI.
+// A workgroup is OSC_W = 4 waves on ONE d-tile: the vectors of the tile sit in LDS once, each wave computes every
+// fourth output block of a product (wave, wave + 4, ...), a workgroup barrier separates the products.  A d-tile's
+// ~1700 MFMAs then run on four SIMDs instead of one: the contraction of a time slice of an ncol-sharded job (17
+// d-tiles) or of ne240 x 128 x 1 (8 d-tiles) was one long wave per d-tile on an otherwise idle chip.
+constexpr int OSC_W = 4;
+
+// Output blocks mb = mb0, mb0 + OSC_W, ... (< MO) of  M . x:  acc = init(mb) + sum_kb blk[mb][kb] . x[kb],  kb < KI.
 // x: the operand tiles in LDS, xl[kb * 64] is this lane's element of tile kb.  The loop over kb is rolled (PF steps
-// per trip, the remainder peeled), the MC accumulators are independent MFMA chains.  Every step issues its block
-// loads unconditionally (past the end: block KI - 1 again, never used): a conditional issue makes the compiler's
-// wait counts conservative, and the first version of this loop waited for all loads in flight at every step.
-template <int MC, int KI, typename Init, typename Out>
+// per trip, the remainder peeled), the accumulators are independent MFMA chains.  Every step issues its block loads
+// unconditionally (past the end: block KI - 1 again, never used; a slot past the last output block: block MO - 1
+// again, discarded): a conditional issue makes the compiler's wait counts conservative, and the first version of
+// this loop waited for all loads in flight at every step.
+template <int MO, int KI, typename Init, typename Out>
 __device__ __forceinline__ void osc_mm(const double* __restrict__ blk, int mb0, const double* xl, uint32_t aoff,
                                        Init init, Out out) {
+  constexpr int MC = (MO + OSC_W - 1) / OSC_W;
   constexpr int PF = OSC_PF < KI ? OSC_PF : KI;
   double acc[MC], ring[PF][MC];
-  const double* __restrict__ b = blk + (size_t)mb0 * KI * 16 + aoff;
+  const double* __restrict__ b[MC];
 #pragma unroll
-  for (int mb = 0; mb < MC; ++mb) acc[mb] = init(mb0 + mb);
+  for (int j = 0; j < MC; ++j) {
+    const int mb = mb0 + j * OSC_W < MO ? mb0 + j * OSC_W : MO - 1;
+    b[j] = blk + (size_t)mb * KI * 16 + aoff;
+    acc[j] = init(mb);
+  }
   static_for<PF - 1>([&](auto pc) __attribute__((always_inline)) {
     constexpr int p = decltype(pc)::value;
 #pragma unroll
-    for (int mb = 0; mb < MC; ++mb) ring[p][mb] = b[(mb * KI + p) * 16];
+    for (int j = 0; j < MC; ++j) ring[p][j] = b[j][p * 16];
   });
   auto step = [&](auto jc, int k) __attribute__((always_inline)) {
-    constexpr int j = decltype(jc)::value;
+    constexpr int r = decltype(jc)::value;
     const int kn = k + PF - 1 < KI ? k + PF - 1 : KI - 1;
 #pragma unroll
-    for (int mb = 0; mb < MC; ++mb) ring[(j + PF - 1) % PF][mb] = b[(mb * KI + kn) * 16];
+    for (int j = 0; j < MC; ++j) ring[(r + PF - 1) % PF][j] = b[j][kn * 16];
     const double x = xl[k * 64];
 #pragma unroll
-    for (int mb = 0; mb < MC; ++mb) acc[mb] = TEMX_MFMA4(ring[j][mb], x, acc[mb]);
+    for (int j = 0; j < MC; ++j) acc[j] = TEMX_MFMA4(ring[r][j], x, acc[j]);
   };
   constexpr int TRIPS = KI / PF, REM = KI % PF;
 #pragma unroll 1
@@ -81,7 +93,8 @@ __device__ __forceinline__ void osc_mm(const double* __restrict__ blk, int mb0, 
     static_for<PF>([&](auto jc) __attribute__((always_inline)) { step(jc, t * PF + decltype(jc)::value); });
   static_for<REM>([&](auto jc) __attribute__((always_inline)) { step(jc, TRIPS * PF + decltype(jc)::value); });
 #pragma unroll
-  for (int mb = 0; mb < MC; ++mb) out(mb0 + mb, acc[mb]);
+  for (int j = 0; j < MC; ++j)
+    if (mb0 + j * OSC_W < MO) out(mb0 + j * OSC_W, acc[j]);
 }
 
 // nf fields: A[f] [KX][Dt] (projections of the shifted field), rho[f] [KR][Drho] (only for f < nout)
@@ -90,19 +103,19 @@ struct OscFieldsIn {
   const double* rho[4];
 };
 
-// LDS doubles per workgroup (= wave)
+// LDS doubles per workgroup
 __host__ __device__ constexpr int osc_fields_lds(int NBK) { return (2 * NBK + 2 * NBK + 4) * 64; }
 __host__ __device__ constexpr int osc_pairs_lds(int NBK) { return (3 * 2 * NBK + 2 * NBK) * 64; }
 
 template <int NBK>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(OSC_W * 64)
 osc_fields_kernel(OscFieldsIn in, OscMats m, int K, int KX, int KR, int NQ, int64_t Dt, int nout,
                   double* __restrict__ B4 /* [nout][K][Dt] */, double* __restrict__ At /* [nf][NQ][Dt] */,
                   double* __restrict__ ab /* [nf][NQ][Dt] */, int64_t Drho, int nts, int nt, int t0) {
   constexpr int NBX = 2 * NBK;
   extern __shared__ double sm[];             // [NBX] a | [NBK] t0 | [NBK] t1 | [4] rho   tiles of 64 lanes
   const int f = blockIdx.y;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int64_t d = (int64_t)blockIdx.x * 16 + c;
   const bool dvalid = d < Dt;
@@ -113,30 +126,12 @@ osc_fields_kernel(OscFieldsIn in, OscMats m, int K, int KX, int KR, int NQ, int6
   double* vt1 = vt0 + NBK * 64;
   double* vr = vt1 + NBK * 64;
   const double* __restrict__ Af = in.A[f];
-#pragma unroll
-  for (int kb = 0; kb < NBX; ++kb) {
+  for (int kb = wave; kb < NBX; kb += OSC_W) {
     const int row = 4 * kb + g;
     const double v = Af[(int64_t)(row < KX ? row : KX - 1) * Dt + dcl];
     va[kb * 64] = row < KX ? v : 0.0;
   }
-  auto zero = [](int) { return 0.0; };
-  // gridDim.z == 2: the synthesis of the field itself, At = Yq A (676 of a wave's 1742 MFMAs at L = 50), does not
-  // depend on alpha and runs in waves of its own (blockIdx.z == 1): twice the waves, a shorter critical path
-  if (gridDim.z == 2 && blockIdx.z == 1) {
-#pragma unroll 1
-    for (int h = 0; h < 2; ++h)
-      osc_mm<NBK, NBX>(m.Yq, h * NBK, va, aoff, zero, [&](int mb, double v) {
-        if (dvalid && 4 * mb + g < NQ) At[((int64_t)f * NQ + 4 * mb + g) * Dt + d] = v;
-      });
-    return;
-  }
-  // (rows >= K of A ride along in the last block of A[:K]: the matrices are zero there)
-  // ---- coefficients of the zonal mean of the shifted field: alpha = T (G2inv (T^T A[:K]))  -> vt0
-  osc_mm<NBK, NBK>(m.Tt, 0, va, aoff, zero, [&](int mb, double v) { vt0[mb * 64] = v; });
-  osc_mm<NBK, NBK>(m.G2inv, 0, vt0, aoff, zero, [&](int mb, double v) { vt1[mb * 64] = v; });
-  osc_mm<NBK, NBK>(m.T, 0, vt1, aoff, zero, [&](int mb, double v) { vt0[mb * 64] = v; });
-  // ---- raw sums of the ORIGINAL field in the plan's basis: B4 = T^T (A[:K] + G[:, :KR] rho)
-  if (f < nout) {
+  if (wave == 0 && f < nout) {
     // the references are those of the whole run ([KR][Drho]); this call may work on the snapshots [t0, t0 + nts)
     const int64_t lev = dcl / nts, dg = lev * nt + t0 + (dcl - lev * nts);
 #pragma unroll
@@ -145,22 +140,41 @@ osc_fields_kernel(OscFieldsIn in, OscMats m, int K, int KX, int KR, int NQ, int6
       const double v = in.rho[f][(int64_t)(row < KR ? row : KR - 1) * Drho + dg];
       vr[kb * 64] = row < KR ? v : 0.0;
     }
-    osc_mm<NBK, 4>(m.Gk, 0, vr, aoff, [&](int mb) { return va[mb * 64]; }, [&](int mb, double v) { vt1[mb * 64] = v; });
-    osc_mm<NBK, NBK>(m.Tt, 0, vt1, aoff, zero, [&](int mb, double v) {
+  }
+  __syncthreads();
+  auto zero = [](int) { return 0.0; };
+  // gridDim.z == 2: the synthesis of the field itself, At = Yq A (676 of a d-tile's 1742 MFMAs at L = 50), does not
+  // depend on alpha and runs in a workgroup of its own (blockIdx.z == 1)
+  if (gridDim.z == 2 && blockIdx.z == 1) {
+    osc_mm<NBX, NBX>(m.Yq, wave, va, aoff, zero, [&](int mb, double v) {
+      if (dvalid && 4 * mb + g < NQ) At[((int64_t)f * NQ + 4 * mb + g) * Dt + d] = v;
+    });
+    return;
+  }
+  // (rows >= K of A ride along in the last block of A[:K]: the matrices are zero there)
+  // ---- coefficients of the zonal mean of the shifted field: alpha = T (G2inv (T^T A[:K]))  -> vt0
+  osc_mm<NBK, NBK>(m.Tt, wave, va, aoff, zero, [&](int mb, double v) { vt0[mb * 64] = v; });
+  __syncthreads();
+  osc_mm<NBK, NBK>(m.G2inv, wave, vt0, aoff, zero, [&](int mb, double v) { vt1[mb * 64] = v; });
+  __syncthreads();
+  osc_mm<NBK, NBK>(m.T, wave, vt1, aoff, zero, [&](int mb, double v) { vt0[mb * 64] = v; });
+  __syncthreads();                           // alpha in vt0; vt1 is free again
+  // ---- raw sums of the ORIGINAL field in the plan's basis: B4 = T^T (A[:K] + G[:, :KR] rho)   (f: block uniform)
+  if (f < nout) {
+    osc_mm<NBK, 4>(m.Gk, wave, vr, aoff, [&](int mb) { return va[mb * 64]; }, [&](int mb, double v) { vt1[mb * 64] = v; });
+    __syncthreads();
+    osc_mm<NBK, NBK>(m.Tt, wave, vt1, aoff, zero, [&](int mb, double v) {
       if (dvalid && 4 * mb + g < K) B4[((int64_t)f * K + 4 * mb + g) * Dt + d] = v;
     });
   }
-  // ---- synthesis at the Gauss-Legendre nodes: ab = Yq[:, :K] alpha, At = Yq A   (NBX output blocks: two halves)
-#pragma unroll 1
-  for (int h = 0; h < 2; ++h) {
-    osc_mm<NBK, NBK>(m.YqK, h * NBK, vt0, aoff, zero, [&](int mb, double v) {
-      if (dvalid && 4 * mb + g < NQ) ab[((int64_t)f * NQ + 4 * mb + g) * Dt + d] = v;
+  // ---- synthesis at the Gauss-Legendre nodes: ab = Yq[:, :K] alpha, At = Yq A
+  osc_mm<NBX, NBK>(m.YqK, wave, vt0, aoff, zero, [&](int mb, double v) {
+    if (dvalid && 4 * mb + g < NQ) ab[((int64_t)f * NQ + 4 * mb + g) * Dt + d] = v;
+  });
+  if (gridDim.z == 1)
+    osc_mm<NBX, NBX>(m.Yq, wave, va, aoff, zero, [&](int mb, double v) {
+      if (dvalid && 4 * mb + g < NQ) At[((int64_t)f * NQ + 4 * mb + g) * Dt + d] = v;
     });
-    if (gridDim.z == 1)
-      osc_mm<NBK, NBX>(m.Yq, h * NBK, va, aoff, zero, [&](int mb, double v) {
-        if (dvalid && 4 * mb + g < NQ) At[((int64_t)f * NQ + 4 * mb + g) * Dt + d] = v;
-      });
-  }
 }
 
 // per pair p: the synthesised fields a = pa(p), b = pb(p) ([NQ][Dt] each) and the projection of their product [K][Dt]
@@ -173,13 +187,13 @@ struct OscPairsIn {
 };
 
 template <int NBK>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(OSC_W * 64)
 osc_pairs_kernel(OscPairsIn in, OscMats m, const double* __restrict__ wq2, int K, int KX, int NQ, int64_t Dt,
                  double* __restrict__ B3 /* [np][K][Dt] */) {
   constexpr int NBX = 2 * NBK;
   extern __shared__ double sm[];             // [NBX] U | [NBX] V | [NBX] c | [NBK] cross | [NBK] F
   const int p = blockIdx.y;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int64_t d = (int64_t)blockIdx.x * 16 + c;
   const bool dvalid = d < Dt;
@@ -195,8 +209,7 @@ osc_pairs_kernel(OscPairsIn in, OscMats m, const double* __restrict__ wq2, int K
   const double* __restrict__ aba = in.ab_a[p];
   const double* __restrict__ abb = in.ab_b[p];
   // ---- products at the nodes:  U_q = w_q (bb At_a + aa At_b),  V_q = w_q aa bb
-#pragma unroll
-  for (int kb = 0; kb < NBX; ++kb) {
+  for (int kb = wave; kb < NBX; kb += OSC_W) {
     const int q = 4 * kb + g;
     const int qc = q < NQ ? q : NQ - 1;
     const double w = q < NQ ? wq2[qc] : 0.0;
@@ -205,22 +218,23 @@ osc_pairs_kernel(OscPairsIn in, OscMats m, const double* __restrict__ wq2, int K
     vU[kb * 64] = w * (bb * ta + aa * tb);
     vV[kb * 64] = w * (aa * bb);
   }
+  __syncthreads();
   auto zero = [](int) { return 0.0; };
   // ---- projected back:  cross_l = sum_q Y_l(x_q) U_q,   c_k = sum_q Y_k(x_q) V_q
-  osc_mm<NBK, NBX>(m.YqKt, 0, vU, aoff, zero, [&](int mb, double v) { vx[mb * 64] = v; });
-#pragma unroll 1
-  for (int h = 0; h < 2; ++h)
-    osc_mm<NBK, NBX>(m.Yqt, h * NBK, vV, aoff, zero, [&](int mb, double v) { vc[mb * 64] = v; });
+  osc_mm<NBK, NBX>(m.YqKt, wave, vU, aoff, zero, [&](int mb, double v) { vx[mb * 64] = v; });
+  osc_mm<NBX, NBX>(m.Yqt, wave, vV, aoff, zero, [&](int mb, double v) { vc[mb * 64] = v; });
+  __syncthreads();
   // ---- F = P - cross + Gx c,  B3 = T^T F
   const double* __restrict__ Pp = in.P[p];
-  osc_mm<NBK, NBX>(m.Gx, 0, vc, aoff,
-              [&](int mb) {
-                const int row = 4 * mb + g;
-                const double v = Pp[(int64_t)(row < K ? row : K - 1) * Dt + dcl];
-                return (row < K ? v : 0.0) - vx[mb * 64];
-              },
-              [&](int mb, double v) { vF[mb * 64] = v; });
-  osc_mm<NBK, NBK>(m.Tt, 0, vF, aoff, zero, [&](int mb, double v) {
+  osc_mm<NBK, NBX>(m.Gx, wave, vc, aoff,
+                   [&](int mb) {
+                     const int row = 4 * mb + g;
+                     const double v = Pp[(int64_t)(row < K ? row : K - 1) * Dt + dcl];
+                     return (row < K ? v : 0.0) - vx[mb * 64];
+                   },
+                   [&](int mb, double v) { vF[mb * 64] = v; });
+  __syncthreads();
+  osc_mm<NBK, NBK>(m.Tt, wave, vF, aoff, zero, [&](int mb, double v) {
     if (dvalid && 4 * mb + g < K) B3[((int64_t)p * K + 4 * mb + g) * Dt + d] = v;
   });
 }

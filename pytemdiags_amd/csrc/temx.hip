@@ -1779,11 +1779,11 @@ static SliceMap slice_map(const temx_plan* pl, int nsl, int64_t rows_total, int6
 template <int NBK>
 static int launch_osc_t(temx_plan* pl, const OscFieldsIn& fin, int nf, int nout, double* Bf, double* At, double* ab,
                         const OscPairsIn& pin, int np, double* Bp, int64_t Dt, hipStream_t st) {
-  const unsigned gx = (unsigned)((Dt + 15) / 16);       // one wave = one workgroup = one d-tile of one field / pair
-  hipLaunchKernelGGL((osc_fields_kernel<NBK>), dim3(gx, nf, 2), dim3(64), (size_t)osc_fields_lds(NBK) * 8, st, fin, pl->osc, pl->K,
+  const unsigned gx = (unsigned)((Dt + 15) / 16);       // one workgroup (OSC_W waves) = one d-tile of one field / pair
+  hipLaunchKernelGGL((osc_fields_kernel<NBK>), dim3(gx, nf, 2), dim3(OSC_W * 64), (size_t)osc_fields_lds(NBK) * 8, st, fin, pl->osc, pl->K,
                      pl->KX, pl->KR, pl->NQ, Dt, nout, Bf, At, ab, pl->D, (int)pl->tnt, (int)pl->nt, (int)pl->tt0);
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL((osc_pairs_kernel<NBK>), dim3(gx, np), dim3(64), (size_t)osc_pairs_lds(NBK) * 8, st, pin, pl->osc, pl->wq2.d(),
+  hipLaunchKernelGGL((osc_pairs_kernel<NBK>), dim3(gx, np), dim3(OSC_W * 64), (size_t)osc_pairs_lds(NBK) * 8, st, pin, pl->osc, pl->wq2.d(),
                      pl->K, pl->KX, pl->NQ, Dt, Bp);
   HIPCHK(hipGetLastError());
   return TEMX_OK;
