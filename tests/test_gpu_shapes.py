@@ -841,7 +841,7 @@ def test_row_map_kernels_on_uneven_classes(monkeypatch, dtype, single):
     plan.close()
 
 
-def test_latitude_noise_of_real_grids_keeps_the_class_sweeps():
+def test_latitude_noise_of_real_grids_keeps_the_class_sweeps(monkeypatch):
     """VERDICT r03 #6.  (a) The natural construction of the cubed sphere (no bit-for-bit mirror rebuild: latitudes of
     a class agree to round-off only) stays on the latitude-class sweeps with the default tolerance and holds the
     fp64 parity tolerance.  (b) fp32 fields: a latitude coordinate with 3e-9 degrees of noise -- far outside the fp64
@@ -874,6 +874,36 @@ def test_latitude_noise_of_real_grids_keeps_the_class_sweeps():
     p0 = engine.Plan(latn, ref.lat, 50)
     assert p0.sweep_mode != 2                                    # fp64 tolerance: no classes on this coordinate
     p0.close()
+    plan = engine.Plan(latn, ref.lat, 50, fp32_fields=True)
+    assert plan.sweep_mode == 2
+    plan.set_tem(nlev, nt, plev * 100)
+    res, _ = plan.tem_run(*[torch.as_tensor(x, device="cuda:0") for x in f32])
+    for i, n in enumerate(_lib.RESULT_NAMES):
+        assert fieldnorm_err(res[i].cpu().numpy(), np.asarray(getattr(ref, n)(), np.float64)) <= 2e-5, n
+    plan.close()
+    # (c) a latitude coordinate that went through float32 (half an ulp at 90 degrees: 3.8e-6 degrees) needs no
+    # tolerance at all: rounding is deterministic, columns whose latitudes agreed before agree after, north and south
+    # round alike.  The class sweeps stay, at the fp64 tolerance, on that coordinate.
+    lat32 = lat_m.astype(np.float32).astype(np.float64)
+    f = synth.analytic_fields(lat32, lon, plev, nt, seed=5)
+    ref = orc.TEMOracle(*f, lat32, plev, mode="factorised")
+    plan = engine.Plan(lat32, ref.lat, 50)
+    assert plan.sweep_mode == 2
+    plan.set_tem(nlev, nt, plev * 100)
+    res, _ = plan.tem_run(*[torch.as_tensor(x, device="cuda:0") for x in f])
+    for i, n in enumerate(_lib.RESULT_NAMES):
+        assert fieldnorm_err(res[i].cpu().numpy(), getattr(ref, n)()) <= 1e-10, n
+    plan.close()
+    # (d) noise that is independent per column and beyond the automatic tolerances (5e-6 degrees) with fp32 fields:
+    # TEMX_SYM_TOL_DEG=1e-5 is the knob -- a basis row then moves by L x 1.7e-7 rad = 9e-6 of its size at worst,
+    # which the 2e-5 of fp32 fields still covers
+    latn = lat_m + rng.uniform(-2.5e-6, 2.5e-6, lat_m.size)
+    f32 = synth.analytic_fields(latn, lon, plev, nt, seed=5, dtype=np.float32)
+    ref = orc.TEMOracle(*f32, latn, plev, mode="factorised")
+    p0 = engine.Plan(latn, ref.lat, 50, fp32_fields=True)
+    assert p0.sweep_mode != 2
+    p0.close()
+    monkeypatch.setenv("TEMX_SYM_TOL_DEG", "1e-5")
     plan = engine.Plan(latn, ref.lat, 50, fp32_fields=True)
     assert plan.sweep_mode == 2
     plan.set_tem(nlev, nt, plev * 100)
