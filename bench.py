@@ -142,11 +142,12 @@ def main():
                     help="do not use the latitude-class sweeps (mirror-paired sweeps on a symmetric grid)")
     ap.add_argument("--no-extras", action="store_true",
                     help="N > 1: skip the legs reported beside the metric (time-sharded configs[2], weak scaling)")
-    ap.add_argument("--also", default="ne30x72x1,ne30x72x91,ne240x128x1:f32,ne120x72x30:f32,ne120x72x30:f64:generic,ne120x72x30:f64:shard1of8,ne120x72x4",
+    ap.add_argument("--also", default="ne30x72x1,ne30x72x91,ne240x128x1:f32,ne120x72x30:f32,ne120x72x30:f64:generic,ne120x72x30:f64:lat32,ne120x72x30:f64:shard1of8,ne120x72x4",
                     help="comma list of the other BASELINE.json shapes, timed after the main one at N=1 "
                          "(shape[:f32|f64][:generic|:shardRofW]; ne30x72x91 is one rank's block of the 730-snapshot config, "
                          "ne120x72x4 a time-sharded rank's block of configs[3] -- the no-collective alternative; "
-                         ":generic forces the generic sweeps -- what a grid without repeated latitudes gets; :shardRofW is "
+                         ":generic forces the generic sweeps -- what a grid without repeated latitudes gets; :lat32 rounds the latitude "
+                         "coordinate through float32 (the class sweeps stay: rounding is deterministic); :shardRofW is "
                          "rank R's step of the job ncol-sharded over W ranks, its collectives left out)")
     ap.add_argument("--exact-mirror", action="store_true",
                     help="build the southern hemisphere of the synthetic grid as the bit-for-bit mirror of the northern one "
@@ -395,6 +396,8 @@ def main():
             ne2, nlev2, nt2 = parse_workload(name)
             try:
                 lat2, lon2 = synth.cubed_sphere_gll(ne2, mirror=args.exact_mirror)
+                if "lat32" in parts[2:]:       # a latitude coordinate that went through float32, as some grid files carry it
+                    lat2 = lat2.astype(np.float32).astype(np.float64)
                 plev2 = synth.pressure_levels(nlev2)
                 sliced = None
                 if shard:
