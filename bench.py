@@ -142,9 +142,10 @@ def main():
                     help="do not use the latitude-class sweeps (mirror-paired sweeps on a symmetric grid)")
     ap.add_argument("--no-extras", action="store_true",
                     help="N > 1: skip the legs reported beside the metric (time-sharded configs[2], weak scaling)")
-    ap.add_argument("--also", default="ne30x72x1,ne30x72x91,ne240x128x1:f32,ne120x72x30:f32,ne120x72x30:f64:generic,ne120x72x30:f64:lat32,ne120x72x30:f64:shard1of8,ne120x72x4",
+    ap.add_argument("--also", default="ne30x72x1,ne30x72x91,ne30x72x92,ne240x128x1:f32,ne120x72x30:f32,ne120x72x30:f64:generic,ne120x72x30:f64:lat32,ne120x72x30:f64:shard1of8,ne120x72x4",
                     help="comma list of the other BASELINE.json shapes, timed after the main one at N=1 "
-                         "(shape[:f32|f64][:generic|:shardRofW]; ne30x72x91 is one rank's block of the 730-snapshot config, "
+                         "(shape[:f32|f64][:generic|:shardRofW]; ne30x72x91 is one rank's block of the 730-snapshot config cut evenly, "
+                         "ne30x72x92 the block TimeShardedTEM cuts with multiple=aligned_snapshots (rows of whole 128-byte lines), "
                          "ne120x72x4 a time-sharded rank's block of configs[3] -- the no-collective alternative; "
                          ":generic forces the generic sweeps -- what a grid without repeated latitudes gets; :lat32 rounds the latitude "
                          "coordinate through float32 (the class sweeps stay: rounding is deterministic); :shardRofW is "

@@ -641,7 +641,9 @@ sweep_os_kernel(FieldPtrs<4> fp, int64_t D, int K, int KX, const double* __restr
 // batch -- or mixes both forms under SGPR pressure.  Issued by hand the loads are invisible to its wait-count
 // pass: row_wait<N>() is the s_waitcnt that makes the named values usable (N = loads issued after them).
 #ifndef TEMX_ROWLOAD_MOD
-#define TEMX_ROWLOAD_MOD "nt"     // cache policy of the row loads (lab A/B: "", "sc1", "sc0 sc1" -- all 8.85-9.02 ms, no difference)
+#define TEMX_ROWLOAD_MOD "nt"     // cache policy of the row loads (lab A/B: "", "sc1", "sc0 sc1" -- all 8.85-9.02 ms, no difference;
+                                  // round 4, rows that are not whole 128-byte lines: "" 2.384 against 2.391 ms on ne30 x 72 x 91 -- the
+                                  // lines two neighbouring windows share are fetched twice under either policy)
 #endif
 template <typename T> struct RowLoad;
 template <> struct RowLoad<double> {
