@@ -369,6 +369,33 @@ reduce_rows_kernel(const double* __restrict__ partial, int nsplit, int64_t strid
   out[idx] = t;
   if (!(fabs(t) <= 1.79769313486231570815e308)) atomicOr(flag, 1);
 }
+// The same sums for many slabs (nsplit > 16: small D, where the pre-pass is cut into many row ranges): sixteen
+// threads per entry, each adding every 16th slab, then the sixteen partial sums in ascending order -- as
+// reduce_partials_kernel does.  (One thread per entry is a chain of nsplit dependent adds: 26 us at nsplit = 128.)
+__global__ void __launch_bounds__(256)
+reduce_rows_wide_kernel(const double* __restrict__ partial, int nsplit, int64_t stride, int nf, int rows_in, int rows,
+                        int64_t D, double* __restrict__ out, int* __restrict__ flag) {
+  __shared__ double sh[16][17];
+  const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int64_t idx = (int64_t)blockIdx.x * 16 + e;
+  const int64_t per = (int64_t)rows * D;
+  const bool ok = idx < per * nf;
+  double s = 0.0;
+  if (ok) {
+    const int64_t f = idx / per, rem = idx - f * per;
+    const double* src = partial + f * rows_in * D + rem;
+    for (int sp = sl; sp < nsplit; sp += 16) s += src[(int64_t)sp * stride];
+  }
+  sh[sl][e] = s;
+  __syncthreads();
+  if (sl == 0 && ok) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += sh[j][e];
+    out[idx] = t;
+    if (!(fabs(t) <= 1.79769313486231570815e308)) atomicOr(flag, 1);
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // solve: C = Ginv . B (harmonic coefficients, pinv(Y0) A = G^-1 Y0^T A, replaces the lstsq of

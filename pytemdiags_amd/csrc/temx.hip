@@ -437,6 +437,20 @@ static int launch_reduce(temx_plan* pl, const double* partial, int nsplit, int64
   return TEMX_OK;
 }
 
+// out[f][r][d] = sum over the slabs of the first `rows` of each field's `rows_in` rows (kernels.hpp)
+static int launch_reduce_rows(temx_plan* pl, const double* partial, int nsplit, int64_t stride, int nf, int rows_in,
+                              int rows, int64_t D, double* out, hipStream_t st) {
+  const int64_t n = (int64_t)nf * rows * D;
+  if (nsplit > 16)
+    hipLaunchKernelGGL(reduce_rows_wide_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, partial, nsplit, stride,
+                       nf, rows_in, rows, D, out, static_cast<int*>(pl->flag.p));
+  else
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, nsplit, stride,
+                       nf, rows_in, rows, D, out, static_cast<int*>(pl->flag.p));
+  HIPCHK(hipGetLastError());
+  return TEMX_OK;
+}
+
 static int launch_solve(temx_plan* pl, const double* B, int NF, int64_t D, double* C, double* Xb,
                         hipStream_t st) {
   if (pl->K <= 64) {   // two small MFMA GEMMs per d-tile
@@ -1806,11 +1820,7 @@ static int os_prepass(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, double* 
   const int64_t D = pl->D, KD4 = (int64_t)4 * pl->KX * D;
   pl->op_valid = pl->c4_valid = pl->tq_valid = pl->os_valid = false;       // no class sums on this path
   if ((rc = launch_sweep_os<0>(pl, fp, dtype, true, pl->rho0.d(), pl->partial.d(), pl->sp_os_s, st))) return rc;
-  const int64_t n = (int64_t)4 * pl->KR * D;
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pl->partial.d(), pl->sp_os_s.nsplit,
-                     KD4, 4, pl->KX, pl->KR, D, As, static_cast<int*>(pl->flag.p));
-  HIPCHK(hipGetLastError());
-  return TEMX_OK;
+  return launch_reduce_rows(pl, pl->partial.d(), pl->sp_os_s.nsplit, KD4, 4, pl->KX, pl->KR, D, As, st);
 }
 
 // 2. reference coefficients from the (global) subsample sums, the sweep, and its reduction: proj = [4 KX + 3 K] rows
@@ -1923,11 +1933,7 @@ static int tracer_os_prepass(temx_plan* pl, int nq, const FieldPtrs<4>& fp, int 
   rc = nq == 2 ? launch_sweep_os<3>(pl, fp, dtype, true, pl->rho0.d(), pl->partial.d(), pl->sp_os_s, st)
                : launch_sweep_os<1>(pl, fp, dtype, true, pl->rho0.d(), pl->partial.d(), pl->sp_os_s, st);
   if (rc) return rc;
-  const int64_t n = (int64_t)nq * pl->KR * D;
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pl->partial.d(), pl->sp_os_s.nsplit,
-                     (int64_t)nq * pl->KX * D, nq, pl->KX, pl->KR, D, Asq, static_cast<int*>(pl->flag.p));
-  HIPCHK(hipGetLastError());
-  return TEMX_OK;
+  return launch_reduce_rows(pl, pl->partial.d(), pl->sp_os_s.nsplit, (int64_t)nq * pl->KX * D, nq, pl->KX, pl->KR, D, Asq, st);
 }
 
 static int tracer_os_sweep(temx_plan* pl, int nq, const FieldPtrs<4>& fp, int dtype, const double* Asq, int nsl, double* projq,
