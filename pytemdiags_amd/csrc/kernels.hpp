@@ -862,20 +862,23 @@ pint_scan_kernel(const double* __restrict__ vb, const double* __restrict__ p, in
 // One thread per zonal grid point; every stencil is recomputed from the seven zonal means
 // (all L1/L2 resident), so the ten GM16 Table-A1 outputs come out of a single launch.
 // zb: [8][M][D] = ub vb thetab wapb upvpb upwappb vptpb int_vbdp.
-// INLINE_INT: int_vbdp (the cumulative trapezoid of vb from the model top, tem_util.py:230-232) is summed
+// INT_MODE 1: int_vbdp (the cumulative trapezoid of vb from the model top, tem_util.py:230-232) is summed
 // by the thread itself -- O(nlev) L1/L2 reads per point instead of a launch of pint_scan_kernel -- and
 // stored to zb[7] for later readers.  Pays for short columns only (the host decides): measured on
 // ne30 x 72 x 1 the loop costs the 5 us the launch saves, on nlev = 128 more.
-template <bool INLINE_INT>
-__global__ void __launch_bounds__(256)
-tem_epilogue_kernel(double* __restrict__ zb, int M, int nlev, int64_t nt, EpiTables tb,
-                    double p0, double* __restrict__ res, double* __restrict__ zon) {
+// INT_MODE 2 (small zonal grids, nlev * nt <= EPI_WG_MAXD): one workgroup per latitude; its waves first run the scan
+// of pint_scan_kernel (same association, same bits) for the latitude's columns into LDS, then the threads walk the
+// latitude's points -- the scan without a launch of its own and without the O(nlev) loop per point of mode 1.
+constexpr int EPI_WG_MAXD = 1024;
+
+template <int INT_MODE>
+__device__ __forceinline__ void tem_epilogue_point(double* __restrict__ zb, int M, int nlev, int64_t nt, const EpiTables& tb,
+                                                   double p0, double* __restrict__ res, double* __restrict__ zon,
+                                                   int64_t idx, double intv_in) {
   // constants.py:6-14 (NB: pi is the reference's truncated value, used by psitem only)
   constexpr double a_e = 6.37123e6, g0 = 9.80665, Hs = 7000.0, pi_ref = 3.14159;
   const int64_t D = (int64_t)nlev * nt;
   const int64_t MD = (int64_t)M * D;
-  const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (idx >= MD) return;
   const int m = (int)(idx / D);
   const int64_t dd = idx % D;
   const int j = (int)(dd / nt);
@@ -892,7 +895,7 @@ tem_epilogue_kernel(double* __restrict__ zb, int M, int nlev, int64_t nt, EpiTab
   auto clj = [&](int jj) { return jj < 0 ? 0 : (jj >= nlev ? nlev - 1 : jj); };
   auto clm = [&](int mm) { return mm < 0 ? 0 : (mm >= M ? M - 1 : mm); };
   double intv0;                              // int_vbdp at (m, j)
-  if constexpr (INLINE_INT) {
+  if constexpr (INT_MODE == 1) {
     double a0 = 0.0, a1 = 0.0;               // two chains: the adds are the critical path
     double vprev = at(vb, m, 0);
     int jj = 1;
@@ -904,6 +907,9 @@ tem_epilogue_kernel(double* __restrict__ zb, int M, int nlev, int64_t nt, EpiTab
     }
     if (jj <= j) a0 += (tb.p[jj] - tb.p[jj - 1]) * (at(vb, m, jj) + vprev) / 2.0;
     intv0 = a0 + a1;
+    zb[7 * MD + idx] = intv0;
+  } else if constexpr (INT_MODE == 2) {
+    intv0 = intv_in;
     zb[7 * MD + idx] = intv0;
   } else {
     intv0 = zb[7 * MD + idx];
@@ -988,6 +994,42 @@ tem_epilogue_kernel(double* __restrict__ zb, int M, int nlev, int64_t nt, EpiTab
     zon[13 * MD + idx] = dpsicos_dlat;
     zon[14 * MD + idx] = dpsi_dp;
     zon[15 * MD + idx] = intv0;
+  }
+}
+
+template <int INT_MODE>
+__global__ void __launch_bounds__(256)
+tem_epilogue_kernel(double* __restrict__ zb, int M, int nlev, int64_t nt, EpiTables tb,
+                    double p0, double* __restrict__ res, double* __restrict__ zon) {
+  const int64_t D = (int64_t)nlev * nt;
+  const int64_t MD = (int64_t)M * D;
+  if constexpr (INT_MODE == 2) {
+    __shared__ double s_int[EPI_WG_MAXD];
+    const int m = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double* v = zb + MD + (int64_t)m * D;       // vb of this latitude, [nlev][nt]
+    for (int64_t t = wave; t < nt; t += 4) {
+      double carry = 0.0;
+      for (int j0 = 0; j0 < nlev; j0 += 64) {
+        const int j = j0 + lane;
+        double term = 0.0;
+        if (j < nlev && j > 0) term = (tb.p[j] - tb.p[j - 1]) * (v[(int64_t)j * nt + t] + v[(int64_t)(j - 1) * nt + t]) / 2.0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const double up = __shfl_up(term, off, 64);
+          if (lane >= off) term += up;
+        }
+        if (j < nlev) s_int[(int64_t)j * nt + t] = carry + term;
+        carry += __shfl(term, 63, 64);
+      }
+    }
+    __syncthreads();
+    for (int64_t dd = threadIdx.x; dd < D; dd += 256)
+      tem_epilogue_point<2>(zb, M, nlev, nt, tb, p0, res, zon, (int64_t)m * D + dd, s_int[dd]);
+  } else {
+    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (idx >= MD) return;
+    tem_epilogue_point<INT_MODE>(zb, M, nlev, nt, tb, p0, res, zon, idx, 0.0);
   }
 }
 

@@ -3064,15 +3064,19 @@ static int tem_stage3_impl(temx_plan* pl, const double* B3, double* results, dou
   // int_vbdp -> zb[7]: by a wavefront scan; inside the epilogue only for short columns on small zonal grids
   // (measured: at nlev = 72 the O(nlev) loop per point costs what the extra launch saves, at 128 more)
   EpiTables tb{pl->p.d(), pl->pg.d(), pl->lg.d(), pl->coslat.d(), pl->fcor.d()};
-  if (pl->nlev > 40 || MD > ((int64_t)1 << 17)) {
+  static const bool epi_wg = !(getenv("TEMX_EPI_WG") && atoi(getenv("TEMX_EPI_WG")) == 0);   // A/B only
+  if (epi_wg && Dt <= EPI_WG_MAXD) {          // small zonal grid: the scan inside the epilogue, one workgroup per latitude
+    hipLaunchKernelGGL(tem_epilogue_kernel<2>, dim3((unsigned)pl->M), dim3(256), 0, st, pl->zb.d(), pl->M, pl->nlev, nts, tb,
+                       pl->p0, results, zonal);
+  } else if (pl->nlev > 40 || MD > ((int64_t)1 << 17)) {
     const int64_t ncols = (int64_t)pl->M * nts;
     hipLaunchKernelGGL(pint_scan_kernel, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st, pl->zb.d() + 1 * MD,
                        pl->p.d(), pl->M, pl->nlev, nts, pl->zb.d() + 7 * MD);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(tem_epilogue_kernel<false>, dim3((unsigned)((MD + 255) / 256)), dim3(256), 0, st, pl->zb.d(),
+    hipLaunchKernelGGL(tem_epilogue_kernel<0>, dim3((unsigned)((MD + 255) / 256)), dim3(256), 0, st, pl->zb.d(),
                        pl->M, pl->nlev, nts, tb, pl->p0, results, zonal);
   } else {
-    hipLaunchKernelGGL(tem_epilogue_kernel<true>, dim3((unsigned)((MD + 255) / 256)), dim3(256), 0, st, pl->zb.d(),
+    hipLaunchKernelGGL(tem_epilogue_kernel<1>, dim3((unsigned)((MD + 255) / 256)), dim3(256), 0, st, pl->zb.d(),
                        pl->M, pl->nlev, nts, tb, pl->p0, results, zonal);
   }
   HIPCHK(hipGetLastError());
