@@ -52,7 +52,12 @@ constexpr int OSC_PF = TEMX_OSC_PF;       // matrix blocks are loaded this many 
 // fourth output block of a product (wave, wave + 4, ...), a workgroup barrier separates the products.  A d-tile's
 // ~1700 MFMAs then run on four SIMDs instead of one: the contraction of a time slice of an ncol-sharded job (17
 // d-tiles) or of ne240 x 128 x 1 (8 d-tiles) was one long wave per d-tile on an otherwise idle chip.
-constexpr int OSC_W = 4;
+// (Eight waves per workgroup, -DTEMX_OSC_W=8, measured 34.9 against 37.0 us for both kernels at ne240 x 128 x 1 and
+// 81.8 against 83.5 at ne120 x 72 x 30: the chain of products and barriers is the cost, not a wave's share of one.)
+#ifndef TEMX_OSC_W
+#define TEMX_OSC_W 4
+#endif
+constexpr int OSC_W = TEMX_OSC_W;
 
 // Output blocks mb = mb0, mb0 + OSC_W, ... (< MO) of  M . x:  acc = init(mb) + sum_kb blk[mb][kb] . x[kb],  kb < KI.
 // x: the operand tiles in LDS, xl[kb * 64] is this lane's element of tile kb.  The loop over kb is rolled (PF steps
