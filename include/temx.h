@@ -37,11 +37,13 @@ enum {
   TEMX_OK = 0,
   TEMX_EINVAL = -1,   /* bad argument */
   TEMX_EHIP = -2,     /* HIP runtime error (no device, launch failure, ...) */
-  TEMX_ENOMEM = -3,   /* device allocation failed */
+  TEMX_ENOMEM = -3,   /* device (or host) allocation failed */
   TEMX_ERANK = -4,    /* Gram matrix has no positive eigenvalue (a rank-deficient Y0 is handled by a
                          pseudo-inverse, like the reference's lstsq) */
   TEMX_ESTATE = -5,   /* call order violated (plan not finalised, TEM levels not set, ...) */
-  TEMX_EUNSUPPORTED = -6
+  TEMX_EUNSUPPORTED = -6,
+  TEMX_EINTERNAL = -7 /* a C++ exception inside the library (reported, never propagated across this ABI);
+                         host allocation failures come back as TEMX_ENOMEM */
 };
 
 enum {
@@ -399,6 +401,11 @@ int temx_mfma_f64_peak(int device, int iters, double* tflops_out);
  * on the launch stream. which: 0 = project sweep, 1 = eddy/flux sweep. */
 int temx_kernel_timing(temx_plan* plan, int enable);
 int temx_kernel_timing_read(temx_plan* plan, int which, double* avg_ms, int* launches);
+
+/* Self-test of the exception barrier of this ABI (needs no device): raises inside the library std::bad_alloc
+ * (kind 0), std::runtime_error (kind 1) or a non-standard exception (kind 2) and must RETURN TEMX_ENOMEM /
+ * TEMX_EINTERNAL / TEMX_EINTERNAL with temx_last_error() set; any other kind returns TEMX_EINVAL. */
+int temx_selftest_exception(int kind);
 
 #ifdef __cplusplus
 }

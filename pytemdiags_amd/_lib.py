@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TEMX_LIB") or os.path.join(_HERE, "libtemx.so")   # TEMX_LIB: A/B builds
 
-ABI_VERSION = 400           # temx_version() of the library these bindings were written for (include/temx.h)
+ABI_VERSION = 401           # temx_version() of the library these bindings were written for (include/temx.h)
 F64, F32 = 0, 1
 DEFER_FINALIZE = 1
 NO_SYMMETRY = 2
@@ -36,7 +36,7 @@ TRACER_ZONAL_NAMES = ("qb", "qpvpb", "qpwappb", "dqb_dp", "qbcoslat", "dqbcoslat
 TRACER_EDDY_NAMES = ("qp", "qpvp", "qpwapp")
 
 ERRORS = {0: "TEMX_OK", -1: "TEMX_EINVAL", -2: "TEMX_EHIP", -3: "TEMX_ENOMEM", -4: "TEMX_ERANK",
-          -5: "TEMX_ESTATE", -6: "TEMX_EUNSUPPORTED"}
+          -5: "TEMX_ESTATE", -6: "TEMX_EUNSUPPORTED", -7: "TEMX_EINTERNAL"}
 
 # every symbol include/temx.h declares: (name, restype, argtypes)
 _vp, _i, _i64, _dp, _u64 = C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_double), C.c_uint64
@@ -91,6 +91,7 @@ SIGNATURES = [
     ("temx_mfma_f64_peak", _i, [_i, _i, _dp]),
     ("temx_kernel_timing", _i, [_vp, _i]),
     ("temx_kernel_timing_read", _i, [_vp, _i, _dp, C.POINTER(_i)]),
+    ("temx_selftest_exception", _i, [_i]),
 ]
 
 

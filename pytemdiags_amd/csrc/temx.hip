@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <atomic>
@@ -2028,17 +2030,25 @@ static int tracer_run_os(temx_plan* pl, int nq, const void* const* q, const void
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
+// No exception may cross the C ABI (the callers are ctypes and C): host allocations (std::bad_alloc) and thread
+// starts (std::system_error) inside an entry point are the sources.  Every multi-statement entry point is a
+// function-try-block ending in TEMX_CATCH.
+#define TEMX_CATCH                                                                                     \
+  catch (const std::bad_alloc&) { return fail(TEMX_ENOMEM, "out of host memory"); }                   \
+  catch (const std::exception& e_) { return fail(TEMX_EINTERNAL, "unexpected C++ exception: %s", e_.what()); } \
+  catch (...) { return fail(TEMX_EINTERNAL, "unexpected C++ exception"); }
+
 extern "C" {
 
-int temx_version(void) { return 400; }
+int temx_version(void) { return 401; }
 
 const char* temx_last_error(void) { return g_err.c_str(); }
 
-int temx_device_count(void) {
+int temx_device_count(void) try {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
-}
+} TEMX_CATCH
 
 void temx_plan_destroy(temx_plan* pl) {
   if (!pl) return;
@@ -2143,7 +2153,7 @@ static int build_all_bases(temx_plan* pl, const double* T) {
 }
 
 int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
-                     const double* lat_deg_host, const double* lat_out_deg_host, int flags) {
+                     const double* lat_deg_host, const double* lat_out_deg_host, int flags) try {
   if (!out || !lat_deg_host || !lat_out_deg_host) return fail(TEMX_EINVAL, "null argument");
   *out = nullptr;
   if (ncol < 1 || M < 1 || L < 0) return fail(TEMX_EINVAL, "ncol, M must be >= 1 and L >= 0");
@@ -2298,17 +2308,17 @@ int temx_plan_create(temx_plan** out, int device, int64_t ncol, int L, int M,
   }
   *out = pl;
   return TEMX_OK;
-}
+} TEMX_CATCH
 
 int temx_plan_is_paired(const temx_plan* pl) { return pl && (pl->sym || pl->cls) ? 1 : 0; }
 
-int temx_plan_sweep_mode(const temx_plan* pl) {
+int temx_plan_sweep_mode(const temx_plan* pl) try {
   return !pl ? -1 : ((pl->cls || (pl->lcls && pl->lone)) ? 2 : (pl->sym ? 1 : 0));
-}
+} TEMX_CATCH
 
-int temx_plan_one_pass(const temx_plan* pl) {
+int temx_plan_one_pass(const temx_plan* pl) try {
   return pl && ((pl->cls && pl->onepass) || (pl->lcls && pl->lone)) ? 1 : 0;
-}
+} TEMX_CATCH
 
 int temx_plan_single_sweep(const temx_plan* pl) { return pl && pl->os_on ? 1 : 0; }
 
@@ -2341,7 +2351,7 @@ static int gram_of_q(temx_plan* pl) {
 // (temx_plan_refine).  The sweeps project on Q, the K x K "solve" multiplies by (Q^T Q)^-1 ~ I, and Qp = Y0p
 // R^-1 takes the coefficients to the output latitudes: errors of order cond(Y0) eps.  Attributes (Y0, Y0p,
 // Y0inv = G^-1 Y0^T) are unchanged.  TEMX_NO_QR=1 keeps the plain normal equations (A/B runs).
-int temx_plan_finalize(temx_plan* pl, const double* G_host) {
+int temx_plan_finalize(temx_plan* pl, const double* G_host) try {
   if (!pl) return fail(TEMX_EINVAL, "null plan");
   HIPCHK(hipSetDevice(pl->device));
   const int K = pl->K;
@@ -2415,9 +2425,9 @@ int temx_plan_finalize(temx_plan* pl, const double* G_host) {
   // one process owns all the rows: second pass of the re-orthogonalisation with its own Gram matrix of Q
   if (want_q && !G_host) return temx_plan_refine(pl, nullptr);
   return TEMX_OK;
-}
+} TEMX_CATCH
 
-int temx_plan_refine(temx_plan* pl, const double* G2_host) {
+int temx_plan_refine(temx_plan* pl, const double* G2_host) try {
   if (!pl) return fail(TEMX_EINVAL, "null plan");
   if (!pl->finalized) return fail(TEMX_ESTATE, "plan not finalised");
   if (!pl->qbasis) return TEMX_OK;                 // normal equations / pseudo-inverse / weights: nothing to refine
@@ -2440,9 +2450,9 @@ int temx_plan_refine(temx_plan* pl, const double* G2_host) {
   if (spd_factor(G2.data(), K, Li) != 0) return TEMX_OK;   // (cannot happen for Q^T Q ~ I; keep the identity)
   inverse_from_factor(Li, K, Gi.data());
   return set_ginv(pl, Gi.data());
-}
+} TEMX_CATCH
 
-int temx_plan_set_weights(temx_plan* pl, const double* w_host) {
+int temx_plan_set_weights(temx_plan* pl, const double* w_host) try {
   if (!pl || !w_host) return fail(TEMX_EINVAL, "null argument");
   HIPCHK(hipSetDevice(pl->device));
   // Y0inv = Y0^T diag(4 pi w)  (sph_zonal_mean.py:181, 385): scale the projection operand rows,
@@ -2479,9 +2489,9 @@ int temx_plan_set_weights(temx_plan* pl, const double* w_host) {
   pl->weighted = true;
   pl->finalized = true;
   return TEMX_OK;
-}
+} TEMX_CATCH
 
-int temx_get_matrix(temx_plan* pl, int which, double* dst, void* stream) {
+int temx_get_matrix(temx_plan* pl, int which, double* dst, void* stream) try {
   if (!pl || !dst) return fail(TEMX_EINVAL, "null argument");
   HIPCHK(hipSetDevice(pl->device));
   hipStream_t st = S_(stream);
@@ -2532,12 +2542,12 @@ int temx_get_matrix(temx_plan* pl, int which, double* dst, void* stream) {
     default:
       return fail(TEMX_EINVAL, "unknown matrix id %d", which);
   }
-}
+} TEMX_CATCH
 
 // ncol-sharded single sweep: the two matrices of build_os_tables that sum over the rows -- Gx = Y0^T Y0ext [K][2L+1]
 // and the Gram matrix of the reference subsample [KR][KR] -- summed over the ranks (all-reduce of
 // temx_get_matrix(TEMX_MAT_GX / TEMX_MAT_GSUB)), handed back.
-int temx_plan_set_os_matrices(temx_plan* pl, const double* Gx_host, const double* Gs_host) {
+int temx_plan_set_os_matrices(temx_plan* pl, const double* Gx_host, const double* Gs_host) try {
   if (!pl || !Gx_host || !Gs_host) return fail(TEMX_EINVAL, "null argument");
   if (!pl->os_built) return fail(TEMX_ESTATE, "the single-sweep tables are not built");
   HIPCHK(hipSetDevice(pl->device));
@@ -2555,10 +2565,10 @@ int temx_plan_set_os_matrices(temx_plan* pl, const double* Gx_host, const double
   pl->os_need_global = false;
   pl->os_valid = false;
   return TEMX_OK;
-}
+} TEMX_CATCH
 
 // ---- operator API --------------------------------------------------------------------------------
-int temx_project(temx_plan* pl, const void* A, int dtype, int64_t D, double* B, void* stream) {
+int temx_project(temx_plan* pl, const void* A, int dtype, int64_t D, double* B, void* stream) try {
   if (!pl || !A || !B) return fail(TEMX_EINVAL, "null argument");
   if (D < 1 || D >= ((int64_t)1 << 28)) return fail(TEMX_EINVAL, "D must be in [1, 2^28)");
   HIPCHK(hipSetDevice(pl->device));
@@ -2575,10 +2585,10 @@ int temx_project(temx_plan* pl, const void* A, int dtype, int64_t D, double* B, 
   int rc = pl->partial.ensure((size_t)sp.nsplit * std::min(pl->K, 64) * D * 8);
   if (rc) return rc;
   return project_all<1>(pl, fp, dtype, D, nullptr, -1, sp, B, S_(stream));
-}
+} TEMX_CATCH
 
 int temx_zonal_mean_from_sums(temx_plan* pl, const double* B, int64_t D, double* out, int native,
-                              void* stream) {
+                              void* stream) try {
   if (!pl || !B || !out) return fail(TEMX_EINVAL, "null argument");
   if (!pl->finalized) return fail(TEMX_ESTATE, "plan not finalised");
   HIPCHK(hipSetDevice(pl->device));
@@ -2587,17 +2597,17 @@ int temx_zonal_mean_from_sums(temx_plan* pl, const double* B, int64_t D, double*
   if ((rc = pl->opC.ensure((size_t)pl->K4 * D * 8))) return rc;
   if ((rc = launch_solve(pl, B, 1, D, pl->opC.d(), nullptr, S_(stream)))) return rc;
   return launch_recon(pl, D, pl->opC.d(), out, S_(stream));
-}
+} TEMX_CATCH
 
 int temx_zonal_mean(temx_plan* pl, const void* A, int dtype, int64_t D, double* out, int native,
-                    void* stream) {
+                    void* stream) try {
   if (!pl || !A || !out) return fail(TEMX_EINVAL, "null argument");
   if (!pl->finalized) return fail(TEMX_ESTATE, "plan not finalised");
   int rc = pl->opB.ensure((size_t)pl->K * std::max<int64_t>(D, 1) * 8);
   if (rc) return rc;
   if ((rc = temx_project(pl, A, dtype, D, pl->opB.d(), stream))) return rc;
   return temx_zonal_mean_from_sums(pl, pl->opB.d(), D, out, native, stream);
-}
+} TEMX_CATCH
 
 // ---- path selection: temx_plan_configure sets the options, the TEMX_* environment variables override them ------
 struct FormChoice {
@@ -2629,7 +2639,7 @@ static bool tracer_one_pass_wanted(const temx_plan* pl) {
   return pl->opt_tracer_one_pass == 1;
 }
 
-int temx_plan_configure(temx_plan* pl, int option, int value) {
+int temx_plan_configure(temx_plan* pl, int option, int value) try {
   if (!pl) return fail(TEMX_EINVAL, "null plan");
   switch (option) {
     case TEMX_OPT_FORM:
@@ -2650,9 +2660,9 @@ int temx_plan_configure(temx_plan* pl, int option, int value) {
   }
   pl->tem = false;                // the choice is made in temx_plan_set_tem: call it (again)
   return TEMX_OK;
-}
+} TEMX_CATCH
 
-int temx_plan_option(const temx_plan* pl, int option) {
+int temx_plan_option(const temx_plan* pl, int option) try {
   if (!pl) return -1;
   switch (option) {
     case TEMX_OPT_FORM: return pl->os_on ? TEMX_FORM_SINGLE_SWEEP : ((pl->cls && pl->onepass) || (pl->lcls && pl->lone) ? TEMX_FORM_CLASS_SUMS : TEMX_FORM_TWO_PASS);
@@ -2664,10 +2674,10 @@ int temx_plan_option(const temx_plan* pl, int option) {
     case TEMX_OPT_OS_CONTRACT: return pl->osc_lds ? 1 : 0;
     default: return -1;
   }
-}
+} TEMX_CATCH
 
 // ---- TEM pipeline --------------------------------------------------------------------------------
-int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_host, double p0) {
+int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_host, double p0) try {
   if (!pl || !p_pa_host) return fail(TEMX_EINVAL, "null argument");
   if (nlev < 2 || nt < 1) return fail(TEMX_EINVAL, "need nlev >= 2 and nt >= 1");
   if ((int64_t)nlev * nt >= ((int64_t)1 << 28)) return fail(TEMX_EINVAL, "nlev*nt must be < 2^28");
@@ -2869,7 +2879,7 @@ int temx_plan_set_tem(temx_plan* pl, int nlev, int64_t nt, const double* p_pa_ho
   }
   pl->tem = true;
   return TEMX_OK;
-}
+} TEMX_CATCH
 
 static int tem_ready(temx_plan* pl) {
   if (!pl) return fail(TEMX_EINVAL, "null plan");
@@ -2879,7 +2889,7 @@ static int tem_ready(temx_plan* pl) {
 }
 
 int temx_tem_stage1(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap,
-                    int dtype, double* B4, void* stream) {
+                    int dtype, double* B4, void* stream) try {
   int rc = tem_ready(pl);
   if (rc) return rc;
   if (!ua || !va || !ta || !wap || !B4) return fail(TEMX_EINVAL, "null argument");
@@ -2919,7 +2929,7 @@ int temx_tem_stage1(temx_plan* pl, const void* ua, const void* va, const void* t
   if ((rc = launch_reduce(pl, pl->partial.d() + 4 * KD, sp.nsplit, 3 * KD, pl->Pq.d(), st, 7 * KD))) return rc;
   pl->op_valid = true;           // csum / Pq now describe these fields (temx_tem_stage2_from_sums)
   return TEMX_OK;
-}
+} TEMX_CATCH
 
 // ---- large-L (K > 64) second sweep: the fused eddy kernel keeps all coefficients of a d-tile in LDS,
 // which stops at 64 harmonics.  Here the native zonal means are materialised by accumulating
@@ -2995,7 +3005,7 @@ static int tem_stage2_large(temx_plan* pl, const FieldPtrs<4>& fp, int dtype, co
 }
 
 int temx_tem_stage2(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap,
-                    int dtype, const double* B4, double* B3, void* stream) {
+                    int dtype, const double* B4, double* B3, void* stream) try {
   int rc = tem_ready(pl);
   if (rc) return rc;
   if (!ua || !va || !ta || !wap || !B4 || !B3) return fail(TEMX_EINVAL, "null argument");
@@ -3012,9 +3022,9 @@ int temx_tem_stage2(temx_plan* pl, const void* ua, const void* va, const void* t
   time_end(pl, 1, st, tl);
   if (rc) return rc;
   return launch_reduce(pl, pl->partial.d(), eddy_slabs(pl), (int64_t)3 * pl->K * pl->D, B3, st);
-}
+} TEMX_CATCH
 
-int temx_tem_stage2_from_sums(temx_plan* pl, const double* B4, double* B3, void* stream) {
+int temx_tem_stage2_from_sums(temx_plan* pl, const double* B4, double* B3, void* stream) try {
   int rc = tem_ready(pl);
   if (rc) return rc;
   if (!B4 || !B3) return fail(TEMX_EINVAL, "null argument");
@@ -3040,9 +3050,9 @@ int temx_tem_stage2_from_sums(temx_plan* pl, const double* B4, double* B3, void*
   // B3 = (projections of u v, u omega, v theta from sweep 1) + (projected corrections)
   return launch_reduce(pl, pl->partial.d(), pl->sp_cflux.nsplit, (int64_t)3 * pl->K * pl->D, B3, st, -1,
                        pl->Pq.d());
-}
+} TEMX_CATCH
 
-int temx_tem_stage3(temx_plan* pl, const double* B3, double* results, double* zonal, void* stream) {
+int temx_tem_stage3(temx_plan* pl, const double* B3, double* results, double* zonal, void* stream) try {
   int rc = tem_ready(pl);
   if (rc) return rc;
   if (!B3 || !results) return fail(TEMX_EINVAL, "null argument");
@@ -3051,7 +3061,7 @@ int temx_tem_stage3(temx_plan* pl, const double* B3, double* results, double* zo
     return fail(TEMX_ESTATE, "the zonal means in the plan are those of a time slice (temx_tem_os_tail); stage 3 needs a "
                              "temx_tem_stage2 / stage2_from_sums on the whole run first");
   return tem_stage3_impl(pl, B3, results, zonal, S_(stream));
-}
+} TEMX_CATCH
 
 // flux zonal means, derivatives, psi, integral and the ten diagnostics for the snapshots of the tail (pl->tnt of them;
 // zb[0..3] hold the zonal means of the four fields for the same snapshots)
@@ -3099,17 +3109,17 @@ static int slices_ok(const temx_plan* pl, int nslices) {
 }
 
 int temx_tem_os_prepass(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap, int dtype,
-                        double* As, void* stream) {
+                        double* As, void* stream) try {
   int rc = os_ready(pl);
   if (rc) return rc;
   if (!ua || !va || !ta || !wap || !As) return fail(TEMX_EINVAL, "null argument");
   if (dtype != TEMX_F64 && dtype != TEMX_F32) return fail(TEMX_EINVAL, "dtype must be TEMX_F64 or TEMX_F32");
   HIPCHK(hipSetDevice(pl->device));
   return os_prepass(pl, four(ua, va, ta, wap), dtype, As, S_(stream));
-}
+} TEMX_CATCH
 
 int temx_tem_os_sweep(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap, int dtype,
-                      const double* As, int nslices, double* proj, void* stream) {
+                      const double* As, int nslices, double* proj, void* stream) try {
   int rc = os_ready(pl);
   if (rc) return rc;
   if (!ua || !va || !ta || !wap || !As || !proj) return fail(TEMX_EINVAL, "null argument");
@@ -3117,10 +3127,10 @@ int temx_tem_os_sweep(temx_plan* pl, const void* ua, const void* va, const void*
   if ((rc = slices_ok(pl, nslices))) return rc;
   HIPCHK(hipSetDevice(pl->device));
   return os_sweep(pl, four(ua, va, ta, wap), dtype, As, nslices, proj, S_(stream));
-}
+} TEMX_CATCH
 
 int temx_tem_os_tail(temx_plan* pl, const double* proj_slice, int64_t t0, int64_t nts, double* results, double* zonal,
-                     void* stream) {
+                     void* stream) try {
   int rc = os_ready(pl);
   if (rc) return rc;
   if (!proj_slice || !results) return fail(TEMX_EINVAL, "null argument");
@@ -3128,7 +3138,7 @@ int temx_tem_os_tail(temx_plan* pl, const double* proj_slice, int64_t t0, int64_
     return fail(TEMX_EINVAL, "snapshots [%lld, %lld) are not inside the run (nt = %lld)", (long long)t0, (long long)(t0 + nts), (long long)pl->nt);
   HIPCHK(hipSetDevice(pl->device));
   return os_tail(pl, proj_slice, t0, nts, results, zonal, S_(stream));
-}
+} TEMX_CATCH
 
 static int tracers_args(const temx_plan* pl, int nq, const void* const* q_host, const void* va, const void* wap, int dtype) {
   if (nq != 1 && nq != 2) return fail(TEMX_EINVAL, "nq = %d: one or two tracers per sweep", nq);
@@ -3140,17 +3150,17 @@ static int tracers_args(const temx_plan* pl, int nq, const void* const* q_host, 
 }
 
 int temx_tracers_os_prepass(temx_plan* pl, int nq, const void* const* q_host, const void* va, const void* wap, int dtype,
-                            double* Asq, void* stream) {
+                            double* Asq, void* stream) try {
   int rc = os_ready(pl);
   if (rc) return rc;
   if ((rc = tracers_args(pl, nq, q_host, va, wap, dtype))) return rc;
   if (!Asq) return fail(TEMX_EINVAL, "null argument");
   HIPCHK(hipSetDevice(pl->device));
   return tracer_os_prepass(pl, nq, tracer_fields(nq, q_host, va, wap), dtype, Asq, S_(stream));
-}
+} TEMX_CATCH
 
 int temx_tracers_os_sweep(temx_plan* pl, int nq, const void* const* q_host, const void* va, const void* wap, int dtype,
-                          const double* Asq, int nslices, double* projq, void* stream) {
+                          const double* Asq, int nslices, double* projq, void* stream) try {
   int rc = os_ready(pl);
   if (rc) return rc;
   if ((rc = tracers_args(pl, nq, q_host, va, wap, dtype))) return rc;
@@ -3158,10 +3168,10 @@ int temx_tracers_os_sweep(temx_plan* pl, int nq, const void* const* q_host, cons
   if ((rc = slices_ok(pl, nslices))) return rc;
   HIPCHK(hipSetDevice(pl->device));
   return tracer_os_sweep(pl, nq, tracer_fields(nq, q_host, va, wap), dtype, Asq, nslices, projq, S_(stream));
-}
+} TEMX_CATCH
 
 int temx_tracers_os_tail(temx_plan* pl, int nq, const double* projq_slice, double* const* tres_host, double* const* tzon_host,
-                         void* stream) {
+                         void* stream) try {
   int rc = os_ready(pl);
   if (rc) return rc;
   if (nq != 1 && nq != 2) return fail(TEMX_EINVAL, "nq = %d: one or two tracers per sweep", nq);
@@ -3171,11 +3181,11 @@ int temx_tracers_os_tail(temx_plan* pl, int nq, const double* projq_slice, doubl
   HIPCHK(hipSetDevice(pl->device));
   if ((rc = tracer_os_ws(pl, nq))) return rc;
   return tracer_os_tail(pl, nq, projq_slice, tres_host, tzon_host, S_(stream));
-}
+} TEMX_CATCH
 
 // stages 2b + 3 on a time slice, from raw sums of any form of the sweeps: B4s [4][K][nlev][nts], B3s [3][K][nlev][nts]
 int temx_tem_tail_from_sums(temx_plan* pl, const double* B4s, const double* B3s, int64_t t0, int64_t nts, double* results,
-                            double* zonal, void* stream) {
+                            double* zonal, void* stream) try {
   int rc = tem_ready(pl);
   if (rc) return rc;
   if (!B4s || !B3s || !results) return fail(TEMX_EINVAL, "null argument");
@@ -3187,21 +3197,21 @@ int temx_tem_tail_from_sums(temx_plan* pl, const double* B4s, const double* B3s,
   pl->c4_valid = pl->os_valid = false;                        // zb describes the slice from here on
   if ((rc = launch_solve(pl, B4s, 4, pl->tD, nullptr, pl->zb.d(), st))) return rc;
   return tem_stage3_impl(pl, B3s, results, zonal, st);
-}
+} TEMX_CATCH
 
 // Cut rows of [nlev][nt] columns into the time slices a reduce-scatter wants: out[w][row][lev][t - t0(w)], slice w
 // padded to rows * nlev * ceil(nt / nslices) doubles (kernels.hpp, SliceMap).
-int temx_time_slices(temx_plan* pl, const double* B, int64_t rows, int nslices, double* out, void* stream) {
+int temx_time_slices(temx_plan* pl, const double* B, int64_t rows, int nslices, double* out, void* stream) try {
   int rc = tem_ready(pl);
   if (rc) return rc;
   if (!B || !out || rows < 1) return fail(TEMX_EINVAL, "bad argument");
   if ((rc = slices_ok(pl, nslices))) return rc;
   HIPCHK(hipSetDevice(pl->device));
   return launch_reduce(pl, B, 1, rows * pl->D, out, S_(stream), -1, nullptr, slice_map(pl, nslices, rows, 0));
-}
+} TEMX_CATCH
 
 int temx_tem_run(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap,
-                 int dtype, double* results, double* zonal, void* stream) {
+                 int dtype, double* results, double* zonal, void* stream) try {
   int rc = tem_ready(pl);
   if (rc) return rc;
   if (os_active(pl, dtype)) {
@@ -3218,10 +3228,10 @@ int temx_tem_run(temx_plan* pl, const void* ua, const void* va, const void* ta, 
     rc = temx_tem_stage2(pl, ua, va, ta, wap, dtype, pl->B4.d(), pl->B3.d(), stream);
   if (rc) return rc;
   return temx_tem_stage3(pl, pl->B3.d(), results, zonal, stream);
-}
+} TEMX_CATCH
 
 int temx_tem_eddy(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap,
-                  int dtype, double* const* eddy_ptrs_host, void* stream) {
+                  int dtype, double* const* eddy_ptrs_host, void* stream) try {
   int rc = tem_ready(pl);
   if (rc) return rc;
   if (!ua || !va || !ta || !wap || !eddy_ptrs_host) return fail(TEMX_EINVAL, "null argument");
@@ -3235,10 +3245,10 @@ int temx_tem_eddy(temx_plan* pl, const void* ua, const void* va, const void* ta,
                                  pl->colscale.d(), eo, S_(stream));
   }
   return run_eddy<0>(pl, four(ua, va, ta, wap), dtype, pl->C4.d(), nullptr, &eo, S_(stream));
-}
+} TEMX_CATCH
 
 int temx_tem_eddy_rows(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap,
-                       int dtype, int64_t row0, int64_t nrows, double* const* eddy_ptrs_host, void* stream) {
+                       int dtype, int64_t row0, int64_t nrows, double* const* eddy_ptrs_host, void* stream) try {
   int rc = tem_ready(pl);
   if (rc) return rc;
   if (!ua || !va || !ta || !wap || !eddy_ptrs_host) return fail(TEMX_EINVAL, "null argument");
@@ -3265,7 +3275,7 @@ int temx_tem_eddy_rows(temx_plan* pl, const void* ua, const void* va, const void
   EddyOut eo;
   for (int i = 0; i < TEMX_NEDDY; ++i) eo.p[i] = eddy_ptrs_host[i];
   return launch_eddy_from_xbar(pl, fp, dtype, xb, pl->colscale.d(), eo, st, nrows);
-}
+} TEMX_CATCH
 
 // ---- tracer TEM -----------------------------------------------------------------------------------
 static int tracer_ws(temx_plan* pl) {
@@ -3279,7 +3289,7 @@ static int tracer_ws(temx_plan* pl) {
   return pl->partial.ensure(std::max(need, pl->partial.bytes));
 }
 
-int temx_tracer_stage1(temx_plan* pl, const void* q, int dtype, double* Bq, void* stream) {
+int temx_tracer_stage1(temx_plan* pl, const void* q, int dtype, double* Bq, void* stream) try {
   int rc = tem_ready(pl);
   if (rc) return rc;
   if (!q || !Bq) return fail(TEMX_EINVAL, "null argument");
@@ -3295,10 +3305,10 @@ int temx_tracer_stage1(temx_plan* pl, const void* q, int dtype, double* Bq, void
                : launch_project<1>(pl, fp, dtype, pl->D, nullptr, -1, pl->partial.d(), sp, S_(stream));
   if (rc) return rc;
   return launch_reduce(pl, pl->partial.d(), sp.nsplit, (int64_t)pl->K * pl->D, Bq, S_(stream));
-}
+} TEMX_CATCH
 
 int temx_tracer_stage2(temx_plan* pl, const void* q, const void* va, const void* wap, int dtype,
-                       const double* Bq, double* Bq2, void* stream) {
+                       const double* Bq, double* Bq2, void* stream) try {
   int rc = tem_ready(pl);
   if (rc) return rc;
   if (!q || !va || !wap || !Bq || !Bq2) return fail(TEMX_EINVAL, "null argument");
@@ -3330,9 +3340,9 @@ int temx_tracer_stage2(temx_plan* pl, const void* q, const void* va, const void*
   HIPCHK(hipMemcpyAsync((char*)pl->Ct.p + 2 * slab, (char*)pl->C4.p + 3 * slab, slab, hipMemcpyDeviceToDevice, st));
   if ((rc = run_eddy<1>(pl, four(q, va, wap, nullptr), dtype, pl->Ct.d(), pl->partial.d(), nullptr, st))) return rc;
   return launch_reduce(pl, pl->partial.d(), eddy_slabs(pl), (int64_t)2 * pl->K * pl->D, Bq2, st);
-}
+} TEMX_CATCH
 
-int temx_tracer_stage3(temx_plan* pl, const double* Bq2, double* tres, double* tzon, void* stream) {
+int temx_tracer_stage3(temx_plan* pl, const double* Bq2, double* tres, double* tzon, void* stream) try {
   int rc = tem_ready(pl);
   if (rc) return rc;
   if (!Bq2 || !tres) return fail(TEMX_EINVAL, "null argument");
@@ -3340,7 +3350,7 @@ int temx_tracer_stage3(temx_plan* pl, const double* Bq2, double* tres, double* t
   if (!tail_is_whole(pl)) return fail(TEMX_ESTATE, "the plan holds the zonal means of a time slice (temx_tem_os_tail)");
   HIPCHK(hipSetDevice(pl->device));
   return tracer_stage3_impl(pl, Bq2, tres, tzon, S_(stream));
-}
+} TEMX_CATCH
 
 static int tracer_stage3_impl(temx_plan* pl, const double* Bq2, double* tres, double* tzon, hipStream_t st) {
   int rc;
@@ -3359,7 +3369,7 @@ static int tracer_stage3_impl(temx_plan* pl, const double* Bq2, double* tres, do
 static inline bool tracer_one_pass(const temx_plan* pl) { return pl->cls && pl->onepass && pl->op_valid; }
 
 int temx_tracer_stage1_sums(temx_plan* pl, const void* q, const void* va, const void* wap, int dtype,
-                            double* Bq, void* stream) {
+                            double* Bq, void* stream) try {
   int rc = tem_ready(pl);
   if (rc) return rc;
   if (!q || !va || !wap || !Bq) return fail(TEMX_EINVAL, "null argument");
@@ -3380,9 +3390,9 @@ int temx_tracer_stage1_sums(temx_plan* pl, const void* q, const void* va, const 
   if ((rc = launch_reduce(pl, pl->partial.d() + KD, sp.nsplit, 2 * KD, pl->Pq2.d(), st, 3 * KD))) return rc;
   pl->tq_valid = true;
   return TEMX_OK;
-}
+} TEMX_CATCH
 
-int temx_tracer_stage2_from_sums(temx_plan* pl, const double* Bq, double* Bq2, void* stream) {
+int temx_tracer_stage2_from_sums(temx_plan* pl, const double* Bq, double* Bq2, void* stream) try {
   int rc = tem_ready(pl);
   if (rc) return rc;
   if (!Bq || !Bq2) return fail(TEMX_EINVAL, "null argument");
@@ -3403,13 +3413,13 @@ int temx_tracer_stage2_from_sums(temx_plan* pl, const double* Bq, double* Bq2, v
   // Bq2 = (projected co-moments of q v, q omega from the sweep) + (projected n (m_q - qb)(m_v - vb) terms)
   return launch_reduce(pl, pl->partial.d(), pl->sp_cflux.nsplit, (int64_t)2 * pl->K * pl->D, Bq2, st, -1,
                        pl->Pq2.d());
-}
+} TEMX_CATCH
 
 // TEM stage 1 and the tracer's one-pass stage 1 in ONE sweep over (u, v, T, omega, q): the fields are read once
 // for both (40 B per grid point instead of 32 + 24).  State afterwards: as after temx_tem_stage1 followed by
 // temx_tracer_stage1_sums.
 int temx_tem_tracer_stage1(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap,
-                           const void* q, int dtype, double* B4, double* Bq, void* stream) {
+                           const void* q, int dtype, double* B4, double* Bq, void* stream) try {
   int rc = tem_ready(pl);
   if (rc) return rc;
   if (!ua || !va || !ta || !wap || !q || !B4 || !Bq) return fail(TEMX_EINVAL, "null argument");
@@ -3443,11 +3453,11 @@ int temx_tem_tracer_stage1(temx_plan* pl, const void* ua, const void* va, const 
   pl->op_valid = true;
   pl->tq_valid = true;
   return TEMX_OK;
-}
+} TEMX_CATCH
 
 int temx_tem_tracer_run(temx_plan* pl, const void* ua, const void* va, const void* ta, const void* wap,
                         const void* q, int dtype, double* results, double* zonal, double* tres, double* tzon,
-                        void* stream) {
+                        void* stream) try {
   int rc = tem_ready(pl);
   if (rc) return rc;
   if (!q || !tres) return fail(TEMX_EINVAL, "null argument");
@@ -3462,10 +3472,10 @@ int temx_tem_tracer_run(temx_plan* pl, const void* ua, const void* va, const voi
   if ((rc = temx_tem_stage3(pl, pl->B3.d(), results, zonal, stream))) return rc;
   if ((rc = temx_tracer_stage2_from_sums(pl, pl->Bq.d(), pl->Bq2.d(), stream))) return rc;
   return temx_tracer_stage3(pl, pl->Bq2.d(), tres, tzon, stream);
-}
+} TEMX_CATCH
 
 int temx_tracer_run(temx_plan* pl, const void* q, const void* va, const void* wap, int dtype,
-                    double* tres, double* tzon, void* stream) {
+                    double* tres, double* tzon, void* stream) try {
   int rc = tem_ready(pl);
   if (rc) return rc;
   if (pl->os_valid && pl->c4_valid && tail_is_whole(pl) && os_active(pl, dtype)) {   // after a single-sweep TEM run: the tracer's single sweep
@@ -3489,13 +3499,13 @@ int temx_tracer_run(temx_plan* pl, const void* q, const void* va, const void* wa
   if ((rc = temx_tracer_stage1(pl, q, dtype, pl->Bq.d(), stream))) return rc;
   if ((rc = temx_tracer_stage2(pl, q, va, wap, dtype, pl->Bq.d(), pl->Bq2.d(), stream))) return rc;
   return temx_tracer_stage3(pl, pl->Bq2.d(), tres, tzon, stream);
-}
+} TEMX_CATCH
 
 // nq tracers of one TEM run (tem_diagnostics.py:281-301 takes a list): after a single-sweep TEM run they are swept
 // in PAIRS -- (q1, q2, v, omega) read once: the traffic of the TEM sweep for two tracers instead of 3/4 of it for each
 // -- and a last odd one alone; on any other path one temx_tracer_run after the other.
 int temx_tracers_run(temx_plan* pl, int nq, const void* const* q_host, const void* va, const void* wap, int dtype,
-                     double* const* tres_host, double* const* tzon_host, void* stream) {
+                     double* const* tres_host, double* const* tzon_host, void* stream) try {
   int rc = tem_ready(pl);
   if (rc) return rc;
   if (nq < 1 || !q_host || !tres_host) return fail(TEMX_EINVAL, "bad argument");
@@ -3514,10 +3524,10 @@ int temx_tracers_run(temx_plan* pl, int nq, const void* const* q_host, const voi
   for (; i < nq; ++i)
     if ((rc = temx_tracer_run(pl, q_host[i], va, wap, dtype, tres_host[i], tzon_host ? tzon_host[i] : nullptr, stream))) return rc;
   return TEMX_OK;
-}
+} TEMX_CATCH
 
 int temx_tracer_eddy(temx_plan* pl, const void* q, const void* va, const void* wap, int dtype,
-                     double* const* ptrs3_host, void* stream) {
+                     double* const* ptrs3_host, void* stream) try {
   int rc = tem_ready(pl);
   if (rc) return rc;
   if (!q || !va || !wap || !ptrs3_host) return fail(TEMX_EINVAL, "null argument");
@@ -3534,9 +3544,9 @@ int temx_tracer_eddy(temx_plan* pl, const void* q, const void* va, const void* w
                                  S_(stream));
   }
   return run_eddy<1>(pl, four(q, va, wap, nullptr), dtype, pl->Ct.d(), nullptr, &eo, S_(stream));
-}
+} TEMX_CATCH
 
-int temx_status(temx_plan* pl, int* nonfinite, void* stream) {
+int temx_status(temx_plan* pl, int* nonfinite, void* stream) try {
   if (!pl || !nonfinite) return fail(TEMX_EINVAL, "null argument");
   HIPCHK(hipSetDevice(pl->device));
   HIPCHK(hipStreamSynchronize(S_(stream)));
@@ -3548,12 +3558,12 @@ int temx_status(temx_plan* pl, int* nonfinite, void* stream) {
     HIPCHK(hipMemcpy(pl->flag.p, &zero, sizeof(int), hipMemcpyHostToDevice));
   }
   return TEMX_OK;
-}
+} TEMX_CATCH
 
 // ---- measurement helpers -------------------------------------------------------------------------
 int temx_synth_fields(int device, int64_t ncol, int nlev, int64_t nt, int64_t t0, const double* lat_deg,
                       const double* lon_deg, const double* plev_hpa, int dtype, uint64_t seed, void* ua,
-                      void* va, void* ta, void* wap, void* stream) {
+                      void* va, void* ta, void* wap, void* stream) try {
   if (!lat_deg || !lon_deg || !plev_hpa || !ua || !va || !ta || !wap) return fail(TEMX_EINVAL, "null argument");
   HIPCHK(hipSetDevice(device));
   dim3 grid(256 * 16), block(256);
@@ -3568,9 +3578,9 @@ int temx_synth_fields(int device, int64_t ncol, int nlev, int64_t nt, int64_t t0
   }
   HIPCHK(hipGetLastError());
   return TEMX_OK;
-}
+} TEMX_CATCH
 
-int temx_mfma_f64_peak(int device, int iters, double* tflops_out) {
+int temx_mfma_f64_peak(int device, int iters, double* tflops_out) try {
   if (!tflops_out || iters < 1) return fail(TEMX_EINVAL, "bad argument");
   HIPCHK(hipSetDevice(device));
   hipDeviceProp_t prop;
@@ -3599,9 +3609,9 @@ int temx_mfma_f64_peak(int device, int iters, double* tflops_out) {
   const double flops = (double)blocks * 4.0 * iters * 8.0 * 512.0;
   *tflops_out = flops / (ms * 1e-3) / 1e12;
   return TEMX_OK;
-}
+} TEMX_CATCH
 
-int temx_kernel_timing(temx_plan* pl, int enable) {
+int temx_kernel_timing(temx_plan* pl, int enable) try {
   if (!pl) return fail(TEMX_EINVAL, "null plan");
   HIPCHK(hipSetDevice(pl->device));
   pl->timing = enable != 0;
@@ -3613,9 +3623,9 @@ int temx_kernel_timing(temx_plan* pl, int enable) {
     pl->timed[w].clear();
   }
   return TEMX_OK;
-}
+} TEMX_CATCH
 
-int temx_kernel_timing_read(temx_plan* pl, int which, double* avg_ms, int* launches) {
+int temx_kernel_timing_read(temx_plan* pl, int which, double* avg_ms, int* launches) try {
   if (!pl || !avg_ms || !launches || which < 0 || which > 1) return fail(TEMX_EINVAL, "bad argument");
   HIPCHK(hipSetDevice(pl->device));
   double tot = 0.0;
@@ -3630,6 +3640,13 @@ int temx_kernel_timing_read(temx_plan* pl, int which, double* avg_ms, int* launc
   *avg_ms = n ? tot / n : 0.0;
   *launches = n;
   return TEMX_OK;
-}
+} TEMX_CATCH
+
+int temx_selftest_exception(int kind) try {
+  if (kind == 0) throw std::bad_alloc();
+  if (kind == 1) throw std::runtime_error("self-test");
+  if (kind == 2) throw 42;
+  return fail(TEMX_EINVAL, "kind must be 0, 1 or 2");
+} TEMX_CATCH
 
 }  // extern "C"

@@ -19,7 +19,7 @@ int main(void) {
       (const void*)temx_plan_configure, (const void*)temx_plan_option, (const void*)temx_plan_set_os_matrices,
       (const void*)temx_tem_os_prepass, (const void*)temx_tem_os_sweep, (const void*)temx_tem_os_tail,
       (const void*)temx_tracers_os_prepass, (const void*)temx_tracers_os_sweep, (const void*)temx_tracers_os_tail, (const void*)temx_tracers_run,
-      (const void*)temx_tem_tail_from_sums, (const void*)temx_time_slices};
+      (const void*)temx_tem_tail_from_sums, (const void*)temx_time_slices, (const void*)temx_selftest_exception};
   unsigned n = (unsigned)(sizeof(syms) / sizeof(syms[0])), i, ok = 0;
   for (i = 0; i < n; ++i) ok += syms[i] != 0;
   /* argument checking happens before any device call: a null plan is an error, not a crash */

@@ -24,6 +24,21 @@ def test_library_exports_every_symbol_of_the_header():
     assert isinstance(lib.temx_last_error(), bytes)
 
 
+def test_no_exception_crosses_the_c_abi():
+    """Every entry point of libtemx.so is a function-try-block: a C++ exception inside comes back as an error code
+    (host allocation failure -> TEMX_ENOMEM, anything else -> TEMX_EINTERNAL), never as std::terminate."""
+    from pytemdiags_amd import _lib
+    lib = _lib.load()
+    assert lib.temx_selftest_exception(0) == -3 and b"memory" in lib.temx_last_error()
+    assert lib.temx_selftest_exception(1) == -7 and b"self-test" in lib.temx_last_error()
+    assert lib.temx_selftest_exception(2) == -7
+    assert lib.temx_selftest_exception(9) == -1
+    src = open(os.path.join(ROOT, "pytemdiags_amd", "csrc", "temx.hip")).read()
+    body = src[src.index('extern "C" {'):src.index('}  // extern "C"')]
+    multi = [m for m in re.finditer(r"^int temx_\w+\([^;{]*\)\s*(try )?\{\s*$", body, re.M)]
+    assert len(multi) >= 40 and all(m.group(1) for m in multi), [m.group(0)[:60] for m in multi if not m.group(1)]
+
+
 def test_engine_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
