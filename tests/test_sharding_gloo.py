@@ -318,7 +318,8 @@ def test_sharded_pipeline_world2_gloo(mode):
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, ret)) for r in range(2)]
+    world = int(os.environ.get("TEMX_GLOO_WORLD", "2"))      # 2 in the suite; more ranks (<= NT) to rehearse by hand
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, ret)) for r in range(world)]
     for p in procs:
         p.start()
     got = ret.get(timeout=120)
