@@ -3,8 +3,8 @@
 //
 // From the projections of the single sweep to the raw sums the rest of the pipeline takes (the algebra is stated at
 // os_contract_kernel; tem_diagnostics.py:547-557 are the products it replaces).  Every step is a small fixed matrix
-// applied to columns, so it runs as 4x4x4 fp64 MFMAs on [4 x 16] tiles of 16 columns: one wave = one d-tile of one
-// field (or of one pair of fields), a tile of a product comes out in the B-operand layout of the next product.  Two
+// applied to columns, so it runs as 16x16x4 fp64 MFMAs on [4 x 16] tiles of 16 columns: one workgroup = one d-tile of
+// one field (or of one pair of fields), a tile of a product comes out in the B-operand layout of the next product.  Two
 // kernels instead of one, because the pair step needs the synthesis of two fields:
 //
 //   osc_fields_kernel  per (field, d-tile):  alpha = T (G2inv (T^T A[:K])),  B4 = T^T (A[:K] + G[:, :KR] rho),
@@ -20,8 +20,8 @@
 // them (the loops are rolled: written unrolled, the compiler hoisted every block load of a product and spilled), and
 // the four waves of a workgroup share one d-tile, each computing every fourth output block of a product.
 //
-// Matrices are 4x4 A-operand blocks built on the host (append_blocks): blk[(mb * NKB + kb) * 16 + k * 4 + i] =
-// M[4 mb + i][4 kb + k], zero padded to whole blocks; a lane's element of a block is at g * 4 + (lane & 3), g = lane >> 4.
+// Matrices are 16 x 4 A-operand blocks built on the host (append_blocks16): blk[(MB * NKB + kb) * 64 + k * 16 + m] =
+// M[16 MB + m][4 kb + k], zero padded to whole blocks; lane (k = lane >> 4, m = lane & 15) loads element `lane` of a block.
 #pragma once
 #include "kernels_op2.hpp"
 
@@ -59,38 +59,52 @@ constexpr int OSC_PF = TEMX_OSC_PF;       // matrix blocks are loaded this many 
 #endif
 constexpr int OSC_W = TEMX_OSC_W;
 
-// Output blocks mb = mb0, mb0 + OSC_W, ... (< MO) of  M . x:  acc = init(mb) + sum_kb blk[mb][kb] . x[kb],  kb < KI.
-// x: the operand tiles in LDS, xl[kb * 64] is this lane's element of tile kb.  The loop over kb is rolled (PF steps
-// per trip, the remainder peeled), the accumulators are independent MFMA chains.  Every step issues its block loads
-// unconditionally (past the end: block KI - 1 again, never used; a slot past the last output block: block MO - 1
-// again, discarded): a conditional issue makes the compiler's wait counts conservative, and the first version of
-// this loop waited for all loads in flight at every step.
+// M . x on 16x16x4 fp64 MFMAs:  out rows [4 mb, 4 mb + 4), mb < MO, = init(mb) + sum_kb M[.., 4 kb .. 4 kb + 3] . x[kb],
+// kb < KI.  One instruction takes a 16 x 4 block of the matrix as its A operand -- 64 distinct doubles, one per
+// lane, a fully coalesced 512-byte load -- against the 4 x 16 operand tile x[kb] (xl[kb * 64] is this lane's element)
+// and accumulates 16 rows x 16 columns: result register i of a lane is row 4 i + g of the block, i.e. the lane's own
+// slot of the 4-row tile 4 MB + i, so a product's output goes to LDS in the operand layout of the next product with no
+// lane movement.  (The first form of this loop used the 4x4x4 instruction with the matrix block shared by its four
+// sub-blocks: every lane group fetched the same 16 doubles, 512 bytes of L1 bandwidth per 512 flop, and the kernels ran
+// at 30 % of the MFMA rate waiting for the texture addresser -- 120 + 83 us at D = 6552.  This form moves a quarter of
+// the bytes per flop.)  Wave w computes the 16-row blocks w, w + OSC_W, ...; the loop over kb is rolled (PF steps per
+// trip, the remainder peeled); every step issues its block loads unconditionally (past the end: block KI - 1 again,
+// never used; a slot past the last 16-row block: the last block again, discarded) -- a conditional issue makes the
+// compiler's wait counts conservative.
+typedef double osc_d4 __attribute__((ext_vector_type(4)));
+
 template <int MO, int KI, typename Init, typename Out>
-__device__ __forceinline__ void osc_mm(const double* __restrict__ blk, int mb0, const double* xl, uint32_t aoff,
+__device__ __forceinline__ void osc_mm(const double* __restrict__ blk, int wave, const double* xl, int lane,
                                        Init init, Out out) {
-  constexpr int MC = (MO + OSC_W - 1) / OSC_W;
+  constexpr int MO16 = (MO + 3) / 4;
+  constexpr int MC = (MO16 + OSC_W - 1) / OSC_W;
   constexpr int PF = OSC_PF < KI ? OSC_PF : KI;
-  double acc[MC], ring[PF][MC];
+  osc_d4 acc[MC];
+  double ring[PF][MC];
   const double* __restrict__ b[MC];
 #pragma unroll
   for (int j = 0; j < MC; ++j) {
-    const int mb = mb0 + j * OSC_W < MO ? mb0 + j * OSC_W : MO - 1;
-    b[j] = blk + (size_t)mb * KI * 16 + aoff;
-    acc[j] = init(mb);
+    const int MB = wave + j * OSC_W < MO16 ? wave + j * OSC_W : MO16 - 1;
+    b[j] = blk + (size_t)MB * KI * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int mb = 4 * MB + i;
+      acc[j][i] = mb < MO ? init(mb) : 0.0;
+    }
   }
   static_for<PF - 1>([&](auto pc) __attribute__((always_inline)) {
     constexpr int p = decltype(pc)::value;
 #pragma unroll
-    for (int j = 0; j < MC; ++j) ring[p][j] = b[j][p * 16];
+    for (int j = 0; j < MC; ++j) ring[p][j] = b[j][p * 64];
   });
   auto step = [&](auto jc, int k) __attribute__((always_inline)) {
     constexpr int r = decltype(jc)::value;
     const int kn = k + PF - 1 < KI ? k + PF - 1 : KI - 1;
 #pragma unroll
-    for (int j = 0; j < MC; ++j) ring[(r + PF - 1) % PF][j] = b[j][kn * 16];
+    for (int j = 0; j < MC; ++j) ring[(r + PF - 1) % PF][j] = b[j][kn * 64];
     const double x = xl[k * 64];
 #pragma unroll
-    for (int j = 0; j < MC; ++j) acc[j] = TEMX_MFMA4(ring[r][j], x, acc[j]);
+    for (int j = 0; j < MC; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[r][j], x, acc[j], 0, 0, 0);
   };
   constexpr int TRIPS = KI / PF, REM = KI % PF;
 #pragma unroll 1
@@ -99,7 +113,13 @@ __device__ __forceinline__ void osc_mm(const double* __restrict__ blk, int mb0, 
   static_for<REM>([&](auto jc) __attribute__((always_inline)) { step(jc, TRIPS * PF + decltype(jc)::value); });
 #pragma unroll
   for (int j = 0; j < MC; ++j)
-    if (mb0 + j * OSC_W < MO) out(mb0 + j * OSC_W, acc[j]);
+    if (wave + j * OSC_W < MO16) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int mb = 4 * (wave + j * OSC_W) + i;
+        if (mb < MO) out(mb, acc[j][i]);
+      }
+    }
 }
 
 // nf fields: A[f] [KX][Dt] (projections of the shifted field), rho[f] [KR][Drho] (only for f < nout)
@@ -125,7 +145,6 @@ osc_fields_kernel(OscFieldsIn in, OscMats m, int K, int KX, int KR, int NQ, int6
   const int64_t d = (int64_t)blockIdx.x * 16 + c;
   const bool dvalid = d < Dt;
   const int64_t dcl = dvalid ? d : Dt - 1;
-  const uint32_t aoff = (uint32_t)(g * 4 + (lane & 3));
   double* va = sm + lane;
   double* vt0 = va + NBX * 64;
   double* vt1 = vt0 + NBK * 64;
@@ -151,33 +170,33 @@ osc_fields_kernel(OscFieldsIn in, OscMats m, int K, int KX, int KR, int NQ, int6
   // gridDim.z == 2: the synthesis of the field itself, At = Yq A (676 of a d-tile's 1742 MFMAs at L = 50), does not
   // depend on alpha and runs in a workgroup of its own (blockIdx.z == 1)
   if (gridDim.z == 2 && blockIdx.z == 1) {
-    osc_mm<NBX, NBX>(m.Yq, wave, va, aoff, zero, [&](int mb, double v) {
+    osc_mm<NBX, NBX>(m.Yq, wave, va, lane, zero, [&](int mb, double v) {
       if (dvalid && 4 * mb + g < NQ) At[((int64_t)f * NQ + 4 * mb + g) * Dt + d] = v;
     });
     return;
   }
   // (rows >= K of A ride along in the last block of A[:K]: the matrices are zero there)
   // ---- coefficients of the zonal mean of the shifted field: alpha = T (G2inv (T^T A[:K]))  -> vt0
-  osc_mm<NBK, NBK>(m.Tt, wave, va, aoff, zero, [&](int mb, double v) { vt0[mb * 64] = v; });
+  osc_mm<NBK, NBK>(m.Tt, wave, va, lane, zero, [&](int mb, double v) { vt0[mb * 64] = v; });
   __syncthreads();
-  osc_mm<NBK, NBK>(m.G2inv, wave, vt0, aoff, zero, [&](int mb, double v) { vt1[mb * 64] = v; });
+  osc_mm<NBK, NBK>(m.G2inv, wave, vt0, lane, zero, [&](int mb, double v) { vt1[mb * 64] = v; });
   __syncthreads();
-  osc_mm<NBK, NBK>(m.T, wave, vt1, aoff, zero, [&](int mb, double v) { vt0[mb * 64] = v; });
+  osc_mm<NBK, NBK>(m.T, wave, vt1, lane, zero, [&](int mb, double v) { vt0[mb * 64] = v; });
   __syncthreads();                           // alpha in vt0; vt1 is free again
   // ---- raw sums of the ORIGINAL field in the plan's basis: B4 = T^T (A[:K] + G[:, :KR] rho)   (f: block uniform)
   if (f < nout) {
-    osc_mm<NBK, 4>(m.Gk, wave, vr, aoff, [&](int mb) { return va[mb * 64]; }, [&](int mb, double v) { vt1[mb * 64] = v; });
+    osc_mm<NBK, 4>(m.Gk, wave, vr, lane, [&](int mb) { return va[mb * 64]; }, [&](int mb, double v) { vt1[mb * 64] = v; });
     __syncthreads();
-    osc_mm<NBK, NBK>(m.Tt, wave, vt1, aoff, zero, [&](int mb, double v) {
+    osc_mm<NBK, NBK>(m.Tt, wave, vt1, lane, zero, [&](int mb, double v) {
       if (dvalid && 4 * mb + g < K) B4[((int64_t)f * K + 4 * mb + g) * Dt + d] = v;
     });
   }
   // ---- synthesis at the Gauss-Legendre nodes: ab = Yq[:, :K] alpha, At = Yq A
-  osc_mm<NBX, NBK>(m.YqK, wave, vt0, aoff, zero, [&](int mb, double v) {
+  osc_mm<NBX, NBK>(m.YqK, wave, vt0, lane, zero, [&](int mb, double v) {
     if (dvalid && 4 * mb + g < NQ) ab[((int64_t)f * NQ + 4 * mb + g) * Dt + d] = v;
   });
   if (gridDim.z == 1)
-    osc_mm<NBX, NBX>(m.Yq, wave, va, aoff, zero, [&](int mb, double v) {
+    osc_mm<NBX, NBX>(m.Yq, wave, va, lane, zero, [&](int mb, double v) {
       if (dvalid && 4 * mb + g < NQ) At[((int64_t)f * NQ + 4 * mb + g) * Dt + d] = v;
     });
 }
@@ -203,7 +222,6 @@ osc_pairs_kernel(OscPairsIn in, OscMats m, const double* __restrict__ wq2, int K
   const int64_t d = (int64_t)blockIdx.x * 16 + c;
   const bool dvalid = d < Dt;
   const int64_t dcl = dvalid ? d : Dt - 1;
-  const uint32_t aoff = (uint32_t)(g * 4 + (lane & 3));
   double* vU = sm + lane;
   double* vV = vU + NBX * 64;
   double* vc = vV + NBX * 64;
@@ -226,12 +244,12 @@ osc_pairs_kernel(OscPairsIn in, OscMats m, const double* __restrict__ wq2, int K
   __syncthreads();
   auto zero = [](int) { return 0.0; };
   // ---- projected back:  cross_l = sum_q Y_l(x_q) U_q,   c_k = sum_q Y_k(x_q) V_q
-  osc_mm<NBK, NBX>(m.YqKt, wave, vU, aoff, zero, [&](int mb, double v) { vx[mb * 64] = v; });
-  osc_mm<NBX, NBX>(m.Yqt, wave, vV, aoff, zero, [&](int mb, double v) { vc[mb * 64] = v; });
+  osc_mm<NBK, NBX>(m.YqKt, wave, vU, lane, zero, [&](int mb, double v) { vx[mb * 64] = v; });
+  osc_mm<NBX, NBX>(m.Yqt, wave, vV, lane, zero, [&](int mb, double v) { vc[mb * 64] = v; });
   __syncthreads();
   // ---- F = P - cross + Gx c,  B3 = T^T F
   const double* __restrict__ Pp = in.P[p];
-  osc_mm<NBK, NBX>(m.Gx, wave, vc, aoff,
+  osc_mm<NBK, NBX>(m.Gx, wave, vc, lane,
                    [&](int mb) {
                      const int row = 4 * mb + g;
                      const double v = Pp[(int64_t)(row < K ? row : K - 1) * Dt + dcl];
@@ -239,7 +257,7 @@ osc_pairs_kernel(OscPairsIn in, OscMats m, const double* __restrict__ wq2, int K
                    },
                    [&](int mb, double v) { vF[mb * 64] = v; });
   __syncthreads();
-  osc_mm<NBK, NBK>(m.Tt, wave, vF, aoff, zero, [&](int mb, double v) {
+  osc_mm<NBK, NBK>(m.Tt, wave, vF, lane, zero, [&](int mb, double v) {
     if (dvalid && 4 * mb + g < K) B3[((int64_t)p * K + 4 * mb + g) * Dt + d] = v;
   });
 }

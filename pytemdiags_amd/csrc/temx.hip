@@ -1639,17 +1639,18 @@ static int build_os_tables(temx_plan* pl) {
   return os_upload_blocks(pl);
 }
 
-// 4x4 A-operand blocks (kernels_osc.hpp) of the R x C matrix A (row-major, leading dimension ld), zero padded to
-// nrb x nkb blocks, appended to `out`
-static void append_blocks(std::vector<double>& out, const double* A, int R, int C, int ld, bool transpose, int nrb, int nkb) {
+// 16 x 4 A-operand blocks (kernels_osc.hpp) of the R x C matrix A (row-major, leading dimension ld): nrb4 blocks of 4
+// rows are padded to whole 16-row blocks, the columns to nkb blocks of 4; zero filled; appended to `out`
+static void append_blocks16(std::vector<double>& out, const double* A, int R, int C, int ld, bool transpose, int nrb4, int nkb) {
   const size_t o = out.size();
-  out.resize(o + (size_t)nrb * nkb * 16, 0.0);
+  const int nrb = (nrb4 + 3) / 4;
+  out.resize(o + (size_t)nrb * nkb * 64, 0.0);
   for (int rb = 0; rb < nrb; ++rb)
     for (int t = 0; t < nkb; ++t)
       for (int k = 0; k < 4; ++k)
-        for (int i = 0; i < 4; ++i) {
-          const int r = 4 * rb + i, c = 4 * t + k;          // element [r][c] of the (transposed) matrix
-          if (r < R && c < C) out[o + ((size_t)rb * nkb + t) * 16 + k * 4 + i] = transpose ? A[(size_t)c * ld + r] : A[(size_t)r * ld + c];
+        for (int m = 0; m < 16; ++m) {
+          const int r = 16 * rb + m, c = 4 * t + k;         // element [r][c] of the (transposed) matrix
+          if (r < R && c < C) out[o + ((size_t)rb * nkb + t) * 64 + k * 16 + m] = transpose ? A[(size_t)c * ld + r] : A[(size_t)r * ld + c];
         }
 }
 
@@ -1664,15 +1665,15 @@ static int os_upload_blocks(temx_plan* pl) {
   size_t off[9];
   const double* T = pl->h_T.data();
   const double* Yq = pl->h_Yq.data();
-  off[0] = blk.size(); append_blocks(blk, T, K, K, K, true, NBK, NBK);                    // T^T
-  off[1] = blk.size(); append_blocks(blk, pl->h_Ginv.data(), K, K, K, false, NBK, NBK);   // G2inv
-  off[2] = blk.size(); append_blocks(blk, T, K, K, K, false, NBK, NBK);                   // T
-  off[3] = blk.size(); append_blocks(blk, pl->h_G.data(), K, KR, K, false, NBK, 4);       // G[:, :KR]
-  off[4] = blk.size(); append_blocks(blk, Yq, NQ, K, KX, false, NBX, NBK);                // Yq[:, :K]
-  off[5] = blk.size(); append_blocks(blk, Yq, NQ, KX, KX, false, NBX, NBX);               // Yq
-  off[6] = blk.size(); append_blocks(blk, Yq, K, NQ, KX, true, NBK, NBX);                 // Yq[:, :K]^T
-  off[7] = blk.size(); append_blocks(blk, Yq, KX, NQ, KX, true, NBX, NBX);                // Yq^T
-  off[8] = blk.size(); append_blocks(blk, pl->h_Gx.data(), K, KX, KX, false, NBK, NBX);   // Gx
+  off[0] = blk.size(); append_blocks16(blk, T, K, K, K, true, NBK, NBK);                    // T^T
+  off[1] = blk.size(); append_blocks16(blk, pl->h_Ginv.data(), K, K, K, false, NBK, NBK);   // G2inv
+  off[2] = blk.size(); append_blocks16(blk, T, K, K, K, false, NBK, NBK);                   // T
+  off[3] = blk.size(); append_blocks16(blk, pl->h_G.data(), K, KR, K, false, NBK, 4);       // G[:, :KR]
+  off[4] = blk.size(); append_blocks16(blk, Yq, NQ, K, KX, false, NBX, NBK);                // Yq[:, :K]
+  off[5] = blk.size(); append_blocks16(blk, Yq, NQ, KX, KX, false, NBX, NBX);               // Yq
+  off[6] = blk.size(); append_blocks16(blk, Yq, K, NQ, KX, true, NBK, NBX);                 // Yq[:, :K]^T
+  off[7] = blk.size(); append_blocks16(blk, Yq, KX, NQ, KX, true, NBX, NBX);                // Yq^T
+  off[8] = blk.size(); append_blocks16(blk, pl->h_Gx.data(), K, KX, KX, false, NBK, NBX);   // Gx
   HIPCHK(hipDeviceSynchronize());              // (a launch in flight may still read the old blocks)
   if (int rc = upload(pl->oscblk, blk.data(), blk.size() * 8)) return rc;
   const double* b = pl->oscblk.d();
