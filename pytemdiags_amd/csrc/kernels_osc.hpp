@@ -52,8 +52,8 @@ constexpr int OSC_PF = TEMX_OSC_PF;       // matrix blocks are loaded this many 
 // fourth output block of a product (wave, wave + 4, ...), a workgroup barrier separates the products.  A d-tile's
 // ~1700 MFMAs then run on four SIMDs instead of one: the contraction of a time slice of an ncol-sharded job (17
 // d-tiles) or of ne240 x 128 x 1 (8 d-tiles) was one long wave per d-tile on an otherwise idle chip.
-// (Eight waves per workgroup, -DTEMX_OSC_W=8, measured 34.9 against 37.0 us for both kernels at ne240 x 128 x 1 and
-// 81.8 against 83.5 at ne120 x 72 x 30: the chain of products and barriers is the cost, not a wave's share of one.)
+// (Build constants measured on the 16x16x4 form, both kernels, D = 2160 / 6552 / 128: W4 PF4 41.8 / 103.7 / 29.1 us,
+// W8 PF4 47.1 / 113.0 / 26.1, W4 PF2 51.8 / 123.1 / 40.5, W8 PF2 47.7 / 122.5 / 34.6, W4 PF6 42.1 / 100.9 / 27.3.)
 #ifndef TEMX_OSC_W
 #define TEMX_OSC_W 4
 #endif
