@@ -333,21 +333,23 @@ reduce_partials_kernel(const double* __restrict__ partial, int nsplit, int64_t s
   }
 }
 
-// Many entries, few slabs (nsplit <= 16): one thread per entry, slabs summed in ascending order --
+// Many entries, few slabs (nsplit <= NS <= 16): one thread per entry, slabs summed in ascending order --
 // the same association as the kernel above (each of its 16 split lanes then holds at most one slab),
-// so both give identical bits.
+// so both give identical bits.  NS = 2, 4, 8 or 16 slots are loaded (a slot past nsplit re-reads slab 0 and adds
+// zero): with 16 slots whatever nsplit, a two-slab sum at D = 6552 spent 32 us on fourteen redundant loads per entry.
+template <int NS>
 __global__ void __launch_bounds__(256)
 reduce_partials_flat_kernel(const double* __restrict__ partial, int nsplit, int64_t stride, int64_t n,
                             const double* __restrict__ addend, double* __restrict__ B, int* __restrict__ flag,
                             SliceMap map) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n) return;
-  double v[16];
+  double v[NS];
 #pragma unroll
-  for (int sp = 0; sp < 16; ++sp) v[sp] = partial[(int64_t)(sp < nsplit ? sp : 0) * stride + idx];
+  for (int sp = 0; sp < NS; ++sp) v[sp] = partial[(int64_t)(sp < nsplit ? sp : 0) * stride + idx];
   double t = 0.0;
 #pragma unroll
-  for (int sp = 0; sp < 16; ++sp) t += sp < nsplit ? v[sp] : 0.0;
+  for (int sp = 0; sp < NS; ++sp) t += sp < nsplit ? v[sp] : 0.0;
   if (addend != nullptr) t += addend[idx];
   B[slice_index(map, idx)] = t;
   if (!(fabs(t) <= 1.79769313486231570815e308)) atomicOr(flag, 1);

@@ -427,8 +427,16 @@ static int launch_reduce(temx_plan* pl, const double* partial, int nsplit, int64
                          const SliceMap& map = SliceMap()) {
   if (stride < 0) stride = n;
   if (nsplit <= 16 && n >= 32768) {   // many entries, few slabs: one thread per entry (same bits)
-    hipLaunchKernelGGL(reduce_partials_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial,
-                       nsplit, stride, n, addend, B, static_cast<int*>(pl->flag.p), map);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    int* flag = static_cast<int*>(pl->flag.p);
+    if (nsplit <= 2)
+      hipLaunchKernelGGL(reduce_partials_flat_kernel<2>, grid, dim3(256), 0, st, partial, nsplit, stride, n, addend, B, flag, map);
+    else if (nsplit <= 4)
+      hipLaunchKernelGGL(reduce_partials_flat_kernel<4>, grid, dim3(256), 0, st, partial, nsplit, stride, n, addend, B, flag, map);
+    else if (nsplit <= 8)
+      hipLaunchKernelGGL(reduce_partials_flat_kernel<8>, grid, dim3(256), 0, st, partial, nsplit, stride, n, addend, B, flag, map);
+    else
+      hipLaunchKernelGGL(reduce_partials_flat_kernel<16>, grid, dim3(256), 0, st, partial, nsplit, stride, n, addend, B, flag, map);
     HIPCHK(hipGetLastError());
     return TEMX_OK;
   }
