@@ -153,7 +153,7 @@ def main():
     ap.add_argument("--exact-mirror", action="store_true",
                     help="build the southern hemisphere of the synthetic grid as the bit-for-bit mirror of the northern one "
                          "(rounds 1-3); default: latitudes as the construction leaves them, equal within a class to round-off")
-    ap.add_argument("--stall-timeout", type=float, default=300.0,
+    ap.add_argument("--stall-timeout", type=float, default=900.0,
                     help="N > 1: seconds the whole run may take before the watchdog reports a stalled collective")
     args = ap.parse_args()
     if args.two_pass:
