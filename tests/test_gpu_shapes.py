@@ -47,6 +47,10 @@ def run_case(ne, nlev, nt, L=50, dtype=np.float64, seed=0):
     (12, 16, 4, 80),    # K = 81, D = 64: large-L class path (class sums first, 2 slices)
     (16, 20, 5, 130),   # K = 131, D = 100: 3 slices, ragged d-tiles
     (30, 16, 4, 200),   # K = 201: 4 slices
+    (8, 128, 8, 50),    # D = 1024, the largest zonal grid of the workgroup-per-latitude epilogue: two 64-level chunks
+                        # of its scan with a carry, two snapshots per wave
+    (8, 130, 7, 20),    # D = 910: ragged second chunk of the scan (130 levels), seven snapshots on four waves
+    (8, 129, 8, 20),    # D = 1032: just past it -- the scan kernel and the one-thread-per-point epilogue
 ])
 def test_pipeline_shapes_fp64(ne, nlev, nt, L):
     run_case(ne, nlev, nt, L)
